@@ -1,0 +1,451 @@
+// Convolution / transposed-convolution layers as implicit GEMM on the gfx950 matrix cores.
+//
+//   D[cout][pixel] += W[cout][k] * X[pixel][k],  k = (tap, channel)
+//
+// fp32 path : v_mfma_f32_16x16x4_f32  (exact fp32 FMA chains -- the parity path)
+// bf16 path : v_mfma_f32_16x16x32_bf16 (fp32 accumulate)
+//
+// Both paths share one byte geometry: a "chunk" is 16 bytes of channels (4 fp32 or 8 bf16), a
+// k-step is 4 chunks = one 64-byte LDS row per operand row.  Lane l of a wave reads row (l&15),
+// chunk (l>>4) with one ds_read_b128; in bf16 that IS the 16x16x32 operand (k = 8*(l>>4)+j), in
+// fp32 the four floats feed four 16x16x4 MFMAs (a permutation of k shared by both operands).
+//
+// Fused into the kernel: the explicit zero padding of the reference (utils.py:408-412 pad() ->
+// predicated loads), bias, LeakyReLU (utils.py:401-405), the concat (tf.concat axis=3 -> the
+// output is written into a channel slice of the consumer's buffer), the antipad crop of the
+// transposed convolution (utils.py:415-421) and its zero-insertion (phase decomposition: four
+// 2x2 stride-1 convolutions, blockIdx.z = phase).
+//
+// Replaces, for the reference, slim.conv2d / slim.conv2d_transpose (cuDNN) at
+// src/flownet_s/flownet_s.py:39-104 and the same call sites in flownet_c/sd/2.
+#include "fn2_common.h"
+
+namespace fn2 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ConvArgs {
+  const void* in;
+  const void* wgt;
+  const float* bias;
+  void* out;
+  int N, H, W, in_cs, in_c0;
+  int cin_chunks;  // chunks per tap
+  int KH, KW, stride, pad;
+  int OH, OW;  // pixel grid of the GEMM (per phase for deconv)
+  int M;       // N*OH*OW
+  int out_H, out_W, out_cs, out_c0, Cout;
+  int ksteps;  // packed row length / 4 chunks
+  int cout_pad;
+  int act;
+  int deconv;
+  int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
+};
+
+template <typename OutT>
+__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+// TC: 16-cout MFMA tiles per wave; WC x WP waves over (cout, pixels); each wave owns 64 pixels.
+template <typename T, typename OutT, int TC, int WC, int WP>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  constexpr int BC = WC * TC * 16;
+  constexpr int BP = WP * 64;
+  constexpr int NT = 256;
+  static_assert(WC * WP == 4, "4 waves per block");
+  constexpr int NPR = BP / 64;                 // pixel-row chunks per thread per k-step
+  constexpr int NWR = (BC * 4 + NT - 1) / NT;  // weight-row chunks per thread per k-step
+  constexpr int WSWZ_BIT = (TC == 4) ? 5 : (TC == 2) ? 4 : 3;
+  __shared__ uint4 lds[2][(BC + BP) * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+  const int cid = tid & 3;  // chunk column this thread stages
+
+  int pad_y = p.pad, pad_x = p.pad, oy_off = 0, ox_off = 0, osc = 1;
+  const T* wgt = reinterpret_cast<const T*>(p.wgt);
+  if (p.deconv) {
+    const int a = blockIdx.z >> 1, b = blockIdx.z & 1;
+    pad_y = 1 - a; pad_x = 1 - b; oy_off = a; ox_off = b; osc = 2;
+    wgt += (size_t)blockIdx.z * p.cout_pad * p.ksteps * 4 * CH;
+  }
+  const int m0 = blockIdx.x * BP;
+  const int c0 = blockIdx.y * BC;
+  const T* in = reinterpret_cast<const T*>(p.in);
+
+  // ---- per-thread staging state
+  int iy0[NPR], ix0[NPR];
+  size_t pbase[NPR];
+  bool pvalid[NPR];
+#pragma unroll
+  for (int q = 0; q < NPR; ++q) {
+    const int m = m0 + (tid >> 2) + 64 * q;
+    pvalid[q] = m < p.M;
+    const int mm = pvalid[q] ? m : 0;
+    const int n = mm / (p.OH * p.OW);
+    const int rem = mm - n * (p.OH * p.OW);
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    iy0[q] = oy * p.stride - pad_y;
+    ix0[q] = ox * p.stride - pad_x;
+    pbase[q] = (size_t)n * p.H * p.W;
+  }
+  const size_t wrow_elems = (size_t)p.ksteps * 4 * CH;
+  // tap state of chunk column `cid`
+  int cc = cid % p.cin_chunks;
+  int tap = cid / p.cin_chunks;
+  int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+  uint4 rp[NPR], rw[NWR];
+  auto load_step = [&](int kt) {
+    const bool tap_ok = ky < p.KH;
+#pragma unroll
+    for (int q = 0; q < NPR; ++q) {
+      const int iy = iy0[q] + ky, ix = ix0[q] + kx;
+      const bool ok = pvalid[q] && tap_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        const T* src = in + (pbase[q] + (size_t)iy * p.W + ix) * p.in_cs + p.in_c0 + cc * CH;
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      rp[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NWR; ++q) {
+      const int e = tid + NT * q;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < BC * 4) {
+        const T* src = wgt + (size_t)(c0 + (e >> 2)) * wrow_elems + ((size_t)kt * 4 + cid) * CH;
+        v = *reinterpret_cast<const uint4*>(src);
+      }
+      rw[q] = v;
+    }
+  };
+  auto advance = [&]() {
+    cc += 4;
+    while (cc >= p.cin_chunks) {
+      cc -= p.cin_chunks;
+      if (++kx == p.KW) { kx = 0; ++ky; }
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < NWR; ++q) {
+      const int e = tid + NT * q;
+      if (e < BC * 4) {
+        const int row = e >> 2;
+        lds[buf][row * 4 + (cid ^ (((row >> WSWZ_BIT) & 1) * 3))] = rw[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NPR; ++q) {
+      const int row = (tid >> 2) + 64 * q;
+      lds[buf][(BC + row) * 4 + (cid ^ (((row >> 3) & 1) * 3))] = rp[q];
+    }
+  };
+
+  // ---- fragment addresses (constant over k)
+  const int fi = lane & 15, fchunk = (lane >> 4) ^ (((fi >> 3) & 1) * 3);
+  int a_off[TC], b_off[4];
+#pragma unroll
+  for (int t = 0; t < TC; ++t)
+    a_off[t] = (wc * TC * 16 + (fi >> 2) * (TC * 4) + t * 4 + (fi & 3)) * 4 + fchunk;
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) b_off[pt] = (BC + wp * 64 + pt * 16 + fi) * 4 + fchunk;
+
+  f32x4 acc[TC][4];
+#pragma unroll
+  for (int t = 0; t < TC; ++t)
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) acc[t][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < p.ksteps; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < p.ksteps;
+    if (more) {
+      advance();
+      load_step(kt + 1);
+    }
+    uint4 fa[TC], fb[4];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) fa[t] = lds[buf][a_off[t]];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) fb[pt] = lds[buf][b_off[pt]];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        if constexpr (sizeof(T) == 2) {
+          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]),
+                                                              __builtin_bit_cast(bf16x8, fb[pt]),
+                                                              acc[t][pt], 0, 0, 0);
+        } else {
+          const float4 va = __builtin_bit_cast(float4, fa[t]), vb = __builtin_bit_cast(float4, fb[pt]);
+          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc[t][pt], 0, 0, 0);
+          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc[t][pt], 0, 0, 0);
+          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, vb.z, acc[t][pt], 0, 0, 0);
+          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, vb.w, acc[t][pt], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, per pixel tile, TC*4 consecutive couts of one pixel
+  OutT* out = reinterpret_cast<OutT*>(p.out);
+  const int cout_base = c0 + wc * TC * 16 + (lane >> 4) * (TC * 4);
+  float bias[TC][4];
+#pragma unroll
+  for (int t = 0; t < TC; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cout_base + t * 4 + r;
+      bias[t][r] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    const int m = m0 + wp * 64 + pt * 16 + fi;
+    if (m >= p.M) continue;
+    const int n = m / (p.OH * p.OW);
+    const int rem = m - n * (p.OH * p.OW);
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    OutT* po = out + (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.out_cs +
+               p.out_c0;
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = acc[t][pt][r] + bias[t][r];
+        if (p.act == FN2_ACT_LEAKY) x = leaky(x);
+        v[r] = x;
+      }
+      const int co = cout_base + t * 4;
+      if (p.vec_ok && co + 3 < p.Cout) {
+        store4<OutT>(po + co, v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.Cout) po[co + r] = from_f32<OutT>(v[r]);
+      }
+    }
+  }
+}
+
+template <typename T, typename OutT>
+static int launch_conv(const ConvArgs& a, int tile, int phases, hipStream_t s) {
+  dim3 block(256);
+  if (tile == 128) {
+    dim3 grid(cdiv(a.M, 128), a.cout_pad / 128, phases);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 4, 2, 2>), grid, block, 0, s, a);
+  } else if (tile == 64) {
+    dim3 grid(cdiv(a.M, 256), a.cout_pad / 64, phases);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 4, 1, 4>), grid, block, 0, s, a);
+  } else if (tile == 32) {
+    dim3 grid(cdiv(a.M, 256), a.cout_pad / 32, phases);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 2, 1, 4>), grid, block, 0, s, a);
+  } else {
+    dim3 grid(cdiv(a.M, 256), a.cout_pad / 16, phases);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 1, 1, 4>), grid, block, 0, s, a);
+  }
+  FN2_CHECK_LAUNCH("conv_igemm");
+  return FN2_OK;
+}
+
+// ---------------------------------------------------------------------------
+// upsample_flowXtoY: 2 -> 2 channel transposed conv 4x4 s2 crop 1, linear (flownet_s.py:60-63).
+// HBM-bound: one lane per output pixel.
+// ---------------------------------------------------------------------------
+template <typename OutT>
+__global__ void __launch_bounds__(256) upsample_flow_kernel(const float* __restrict__ in,
+                                                            const float* __restrict__ w, OutT* __restrict__ out,
+                                                            int N, int H, int W, int out_cs, int out_c0) {
+  __shared__ float sw[64];
+  if (threadIdx.x < 64) sw[threadIdx.x] = w[threadIdx.x];  // [ky][kx][o][i]
+  __syncthreads();
+  const long total = (long)N * 4 * H * W;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(o % (2 * W));
+    const int oy = (int)((o / (2 * W)) % (2 * H));
+    const int n = (int)(o / (2 * W) / (2 * H));
+    const int a = oy & 1, b = ox & 1, y = oy >> 1, x = ox >> 1;
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+      const int iy = y - 1 + a + ty, ky = 3 - a - 2 * ty;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int ix = x - 1 + b + tx, kx = 3 - b - 2 * tx;
+        if (ix < 0 || ix >= W) continue;
+        const float2 v = *reinterpret_cast<const float2*>(in + (((long)n * H + iy) * W + ix) * 2);
+        const float* ww = sw + (ky * 4 + kx) * 4;
+        r0 += v.x * ww[0] + v.y * ww[1];
+        r1 += v.x * ww[2] + v.y * ww[3];
+      }
+    }
+    OutT* po = out + (size_t)o * out_cs + out_c0;
+    po[0] = from_f32<OutT>(r0);
+    po[1] = from_f32<OutT>(r1);
+  }
+}
+
+// images fp32 [n,h,w,3] -> view channels [c_dst, c_dst+3)
+template <typename OutT>
+__global__ void __launch_bounds__(256) pack_image_kernel(const float* __restrict__ img, OutT* __restrict__ out,
+                                                         long npix, long pix0, int out_cs, int c_dst) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float* s = img + i * 3;
+    OutT* d = out + (size_t)(pix0 + i) * out_cs + c_dst;
+    d[0] = from_f32<OutT>(s[0]);
+    d[1] = from_f32<OutT>(s[1]);
+    d[2] = from_f32<OutT>(s[2]);
+  }
+}
+
+static inline int grid_for(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 256L * 16) g = 256L * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static int check_view(const fn2_tensor* t, const char* what) {
+  FN2_REQUIRE(t && t->data, "%s: null tensor", what);
+  FN2_REQUIRE(t->dtype == FN2_F32 || t->dtype == FN2_BF16, "%s: bad dtype", what);
+  FN2_REQUIRE(t->n >= 1 && t->h >= 1 && t->w >= 1 && t->c >= 1, "%s: bad dims", what);
+  FN2_REQUIRE(t->c0 >= 0 && t->c0 + t->c <= t->cs, "%s: channel slice outside the buffer", what);
+  return FN2_OK;
+}
+
+}  // namespace fn2
+
+using namespace fn2;
+
+extern "C" {
+
+int fn2_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16; }
+
+int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
+  FN2_REQUIRE(d, "conv2d: null descriptor");
+  int rc = check_view(&d->in, "conv2d input");
+  if (rc) return rc;
+  rc = check_view(&d->out, "conv2d output");
+  if (rc) return rc;
+  FN2_REQUIRE(d->wgt, "conv2d: null weights");
+  FN2_REQUIRE(d->kind == 0 || d->kind == 1, "conv2d: kind must be 0 (conv) or 1 (deconv)");
+  FN2_REQUIRE(d->in.n == d->out.n, "conv2d: batch mismatch");
+  FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cin_pad >= d->in.c, "conv2d: cin_pad must be a multiple of 8 >= Cin");
+  FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: input channel stride/offset must be multiples of 8");
+  FN2_REQUIRE(d->in.c0 + d->cin_pad <= d->in.cs, "conv2d: padded input channels exceed the buffer stride");
+  const int esz = d->in.dtype == FN2_BF16 ? 2 : 4;
+  const int CH = 16 / esz;
+  FN2_REQUIRE(d->kpad % (4 * CH) == 0, "conv2d: kpad must be a multiple of one k-step");
+  const int tile = fn2_conv2d_cout_tile(d->out.c);
+  FN2_REQUIRE(d->cout_pad % tile == 0 && d->cout_pad >= d->out.c, "conv2d: cout_pad must be a multiple of the cout tile");
+  FN2_REQUIRE(d->act == FN2_ACT_NONE || d->act == FN2_ACT_LEAKY, "conv2d: bad activation");
+  FN2_REQUIRE(d->out.dtype == d->in.dtype || d->out.dtype == FN2_F32, "conv2d: output dtype must be the input dtype or fp32");
+
+  ConvArgs a;
+  a.in = d->in.data; a.wgt = d->wgt; a.bias = d->bias; a.out = d->out.data;
+  a.N = d->in.n; a.H = d->in.h; a.W = d->in.w; a.in_cs = d->in.cs; a.in_c0 = d->in.c0;
+  a.cin_chunks = d->cin_pad / CH;
+  int phases = 1;
+  if (d->kind == 0) {
+    FN2_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->pad >= 0, "conv2d: bad kernel geometry");
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.OH = (d->in.h + 2 * d->pad - d->kh) / d->stride + 1;  // VALID on the padded input
+    a.OW = (d->in.w + 2 * d->pad - d->kw) / d->stride + 1;
+    FN2_REQUIRE(a.OH >= 1 && a.OW >= 1, "conv2d: kernel does not fit");
+    FN2_REQUIRE(d->out.h == a.OH && d->out.w == a.OW, "conv2d: output spatial size %dx%d != expected %dx%d",
+                d->out.h, d->out.w, a.OH, a.OW);
+    a.deconv = 0;
+  } else {
+    FN2_REQUIRE(d->kh == 4 && d->kw == 4 && d->stride == 2, "deconv: only k=4 s=2 crop 1 (flownet_s.py:53-63)");
+    FN2_REQUIRE(d->bias == nullptr, "deconv: the reference transposed convs have no bias (biases_initializer=None)");
+    a.KH = 2; a.KW = 2; a.stride = 1; a.pad = 0;
+    a.OH = d->in.h; a.OW = d->in.w;
+    FN2_REQUIRE(d->out.h == 2 * d->in.h && d->out.w == 2 * d->in.w, "deconv: output must be 2H x 2W");
+    a.deconv = 1;
+    phases = 4;
+  }
+  const long M = (long)a.N * a.OH * a.OW;
+  FN2_REQUIRE(M < (1L << 31), "conv2d: too many output pixels");
+  a.M = (int)M;
+  a.out_H = d->out.h; a.out_W = d->out.w; a.out_cs = d->out.cs; a.out_c0 = d->out.c0; a.Cout = d->out.c;
+  FN2_REQUIRE(d->kpad >= a.KH * a.KW * d->cin_pad, "conv2d: kpad smaller than taps*cin_pad");
+  a.ksteps = d->kpad / (4 * CH);
+  a.cout_pad = d->cout_pad;
+  a.act = d->act;
+  a.vec_ok = (d->out.cs % 4 == 0) && (d->out.c0 % 4 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->in.dtype == FN2_F32) return launch_conv<float, float>(a, tile, phases, s);
+  if (d->out.dtype == FN2_BF16) return launch_conv<bf16_t, bf16_t>(a, tile, phases, s);
+  return launch_conv<bf16_t, float>(a, tile, phases, s);
+}
+
+int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, int n, int h, int wd,
+                      void* stream) {
+  FN2_REQUIRE(in && w, "upsample_flow: null pointer");
+  int rc = check_view(out, "upsample_flow output");
+  if (rc) return rc;
+  FN2_REQUIRE(out->c == 2 && out->n == n && out->h == 2 * h && out->w == 2 * wd,
+              "upsample_flow: output view must be [n, 2h, 2w, 2]");
+  const long total = (long)n * 4 * h * wd;
+  if (out->dtype == FN2_F32)
+    hipLaunchKernelGGL(upsample_flow_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, w, (float*)out->data, n, h, wd, out->cs, out->c0);
+  else
+    hipLaunchKernelGGL(upsample_flow_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, w, (bf16_t*)out->data, n, h, wd, out->cs, out->c0);
+  FN2_CHECK_LAUNCH("upsample_flow");
+  return FN2_OK;
+}
+
+static int pack_one(const float* img, const fn2_tensor* out, int n, int n0, int c_dst, void* stream) {
+  const long npix = (long)n * out->h * out->w, pix0 = (long)n0 * out->h * out->w;
+  if (out->dtype == FN2_F32)
+    hipLaunchKernelGGL(pack_image_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img,
+                       (float*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+  else
+    hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       img, (bf16_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+  FN2_CHECK_LAUNCH("pack_image");
+  return FN2_OK;
+}
+
+int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, void* stream) {
+  FN2_REQUIRE(a && b, "pack_pair: null pointer");
+  int rc = check_view(out, "pack_pair output");
+  if (rc) return rc;
+  FN2_REQUIRE(out->c == 6, "pack_pair: output view must have 6 channels");
+  rc = pack_one(a, out, out->n, 0, 0, stream);
+  if (rc) return rc;
+  return pack_one(b, out, out->n, 0, 3, stream);
+}
+
+int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, void* stream) {
+  FN2_REQUIRE(img, "pack_image: null pointer");
+  int rc = check_view(out, "pack_image output");
+  if (rc) return rc;
+  FN2_REQUIRE(out->c == 3, "pack_image: output view must have 3 channels");
+  FN2_REQUIRE(n_img >= 1 && n0 >= 0 && n0 + n_img <= out->n, "pack_image: rows [n0, n0+n_img) outside the buffer");
+  return pack_one(img, out, n_img, n0, 0, stream);
+}
+
+}  // extern "C"

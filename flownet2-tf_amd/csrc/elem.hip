@@ -1,0 +1,165 @@
+// HBM-bound fused elementwise kernels between the sub-networks of the stacked models.
+// One lane per pixel; the 16-channel (padded) input row of the next network is assembled in
+// registers and written with 16-byte stores, so flow_warp + brightness error + concat
+// (flownet_cs.py:21-36) and ChannelNorm x4 + flow_warp x2 + concat (flownet2.py:25-47) are one
+// pass over the images instead of 6-10 TF nodes.
+#include "fn2_common.h"
+
+namespace fn2 {
+
+// bilinear warp of a 3-channel fp32 image, exact reference rules (flow_warp.cu.cc:44-95)
+__device__ __forceinline__ void warp3(const float* __restrict__ img, long nb, int x, int y, float u, float v,
+                                      int W, int H, float o[3]) {
+  const float x2 = (float)x + u, y2 = (float)y + v;
+  o[0] = o[1] = o[2] = 0.f;
+  if (!((x2 >= 0.f) && (y2 >= 0.f) && (x2 < (float)W) && (y2 < (float)H))) return;
+  const int xL = (int)x2, yT = (int)y2;
+  const int xR = min(xL + 1, W - 1), yB = min(yT + 1, H - 1);
+  const float al = x2 - (float)xL, be = y2 - (float)yT;
+  const float cTL = (1.f - al) * (1.f - be), cTR = al * (1.f - be), cBL = (1.f - al) * be, cBR = al * be;
+  const float* pTL = img + (nb + (long)yT * W + xL) * 3;
+  const float* pTR = img + (nb + (long)yT * W + xR) * 3;
+  const float* pBL = img + (nb + (long)yB * W + xL) * 3;
+  const float* pBR = img + (nb + (long)yB * W + xR) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = cTL * pTL[c] + cTR * pTR[c] + cBL * pBL[c] + cBR * pBR[c];
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store16(OutT* dst, const float v[16]);
+template <>
+__device__ __forceinline__ void store16<float>(float* dst, const float v[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+template <>
+__device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float v[16]) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    bf16x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[8 * q + j];
+    reinterpret_cast<bf16x8*>(dst)[q] = t;
+  }
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(256) stack_input_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ flow, OutT* __restrict__ out,
+                                                          int N, int H, int W, int out_cs, int out_c0) {
+  const long npix = (long)N * H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long nb = (pix / W / H) * (long)H * W;
+    const float2 f = *reinterpret_cast<const float2*>(flow + pix * 2);
+    float wv[3];
+    warp3(b, nb, x, y, f.x, f.y, W, H, wv);
+    float v[16];
+    float e = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float av = a[pix * 3 + c];
+      v[c] = av;
+      v[3 + c] = b[pix * 3 + c];
+      v[6 + c] = wv[c];
+      const float d = av - wv[c];
+      e += d * d;
+    }
+    v[9] = f.x * 0.05f;   // flownet_cs.py:34
+    v[10] = f.y * 0.05f;
+    v[11] = sqrtf(e);     // brightness error, flownet_cs.py:24-27
+    v[12] = v[13] = v[14] = v[15] = 0.f;
+    store16<OutT>(out + (size_t)pix * out_cs + out_c0, v);
+  }
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(256) fusion_input_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ fsd,
+                                                           const float* __restrict__ fcss, OutT* __restrict__ out,
+                                                           int N, int H, int W, int out_cs, int out_c0) {
+  const long npix = (long)N * H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long nb = (pix / W / H) * (long)H * W;
+    const float2 sd = *reinterpret_cast<const float2*>(fsd + pix * 2);
+    const float2 cs = *reinterpret_cast<const float2*>(fcss + pix * 2);
+    float wsd[3], wcs[3];
+    warp3(b, nb, x, y, sd.x, sd.y, W, H, wsd);  // flownet2.py:33
+    warp3(b, nb, x, y, cs.x, cs.y, W, H, wcs);  // flownet2.py:37
+    float v[16];
+    float esd = 0.f, ecs = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float av = a[pix * 3 + c];
+      v[c] = av;
+      const float d1 = av - wsd[c], d2 = av - wcs[c];
+      esd += d1 * d1;
+      ecs += d2 * d2;
+    }
+    v[3] = sd.x; v[4] = sd.y; v[5] = cs.x; v[6] = cs.y;           // flownet2.py:41-43
+    v[7] = sqrtf(sd.x * sd.x + sd.y * sd.y);                       // ChannelNorm(flow_sd), :30
+    v[8] = sqrtf(cs.x * cs.x + cs.y * cs.y);                       // ChannelNorm(flow_css), :31
+    v[9] = sqrtf(esd);                                             // :35
+    v[10] = sqrtf(ecs);                                            // :39
+    v[11] = v[12] = v[13] = v[14] = v[15] = 0.f;
+    store16<OutT>(out + (size_t)pix * out_cs + out_c0, v);
+  }
+}
+
+static inline int grid_for(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 256L * 16) g = 256L * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static int check_out16(const fn2_tensor* out, int c, const char* what) {
+  FN2_REQUIRE(out && out->data, "%s: null output", what);
+  FN2_REQUIRE(out->c == c, "%s: output view must have %d channels", what, c);
+  FN2_REQUIRE(out->cs % 8 == 0 && out->c0 % 8 == 0 && out->c0 + 16 <= out->cs,
+              "%s: output needs a 16-channel, 8-aligned slot", what);
+  FN2_REQUIRE(out->dtype == FN2_F32 || out->dtype == FN2_BF16, "%s: bad dtype", what);
+  return FN2_OK;
+}
+
+}  // namespace fn2
+
+using namespace fn2;
+
+extern "C" {
+
+int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out, void* stream) {
+  FN2_REQUIRE(a && b && flow, "stack_input: null pointer");
+  int rc = check_out16(out, 12, "stack_input");
+  if (rc) return rc;
+  const long npix = (long)out->n * out->h * out->w;
+  if (out->dtype == FN2_F32)
+    hipLaunchKernelGGL(stack_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, flow, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  else
+    hipLaunchKernelGGL(stack_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, flow, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  FN2_CHECK_LAUNCH("stack_input");
+  return FN2_OK;
+}
+
+int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const float* flow_css,
+                     const fn2_tensor* out, void* stream) {
+  FN2_REQUIRE(a && b && flow_sd && flow_css, "fusion_input: null pointer");
+  int rc = check_out16(out, 11, "fusion_input");
+  if (rc) return rc;
+  const long npix = (long)out->n * out->h * out->w;
+  if (out->dtype == FN2_F32)
+    hipLaunchKernelGGL(fusion_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, flow_sd, flow_css, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  else
+    hipLaunchKernelGGL(fusion_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, flow_sd, flow_css, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  FN2_CHECK_LAUNCH("fusion_input");
+  return FN2_OK;
+}
+
+}  // extern "C"

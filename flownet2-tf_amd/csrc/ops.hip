@@ -1,0 +1,472 @@
+// Op-surface kernels (float32, dense NHWC) and small HBM-bound engine kernels.
+// gfx950 only.  Semantics follow the reference kernels cited per function; the
+// implementation does not (no materialised padding, no 1024-thread transposes,
+// no default-stream memsets).
+#include "fn2_common.h"
+
+namespace fn2 {
+
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---------------------------------------------------------------------------
+// correlation, generic attributes (any odd k, s1, s2, pad): one thread per
+// output element.  Fallback only -- the model's call site (k=1, s1=1, pad=md)
+// goes through the MFMA kernel in corr.hip.
+//   out[n,y,x,d] = 1/(k*k*C) sum_{j,i,c} A0[n,y1+j,x1+i,c]*B0[n,y1+s2p+j,x1+s2o+i,c]
+//   (correlation_kernel.cu.cc:45-110), A0/B0 = inputs zero-extended by `pad`.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) correlation_generic_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int N, int H,
+    int W, int C, int k, int md, int s1, int s2, int pad, int oh, int ow, int gr, int gw) {
+  const int D = gw * gw;
+  const long total = (long)N * oh * ow * D;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(idx % D);
+    const int x = (int)((idx / D) % ow);
+    const int y = (int)((idx / D / ow) % oh);
+    const int n = (int)(idx / D / ow / oh);
+    const int s2o = (d % gw - gr) * s2;
+    const int s2p = (d / gw - gr) * s2;
+    // top-left of the patch in UNPADDED coordinates
+    const int ya = y * s1 + md - pad, xa = x * s1 + md - pad;
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int y1 = ya + j, y2 = ya + j + s2p;
+      if (y1 < 0 || y1 >= H || y2 < 0 || y2 >= H) continue;
+      for (int i = 0; i < k; ++i) {
+        const int x1 = xa + i, x2 = xa + i + s2o;
+        if (x1 < 0 || x1 >= W || x2 < 0 || x2 >= W) continue;
+        const float* pa = a + (((long)n * H + y1) * W + x1) * C;
+        const float* pb = b + (((long)n * H + y2) * W + x2) * C;
+        int c = 0;
+        if ((C & 3) == 0) {
+          for (; c < C; c += 4) {
+            const float4 va = *reinterpret_cast<const float4*>(pa + c);
+            const float4 vb = *reinterpret_cast<const float4*>(pb + c);
+            acc += va.x * vb.x + va.y * vb.y + va.z * vb.z + va.w * vb.w;
+          }
+        } else {
+          for (; c < C; ++c) acc += pa[c] * pb[c];
+        }
+      }
+    }
+    out[idx] = acc / (float)(k * k * C);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// correlation backward (correlation_grad_kernel.cu.cc:20-189): one thread per
+// input element, both gradients in one pass over the displacement grid.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int ceil_div_any(int num, int den) {  // ROUND_OFF trick, :5,:51-63
+  return (num >= 0) ? (num + den - 1) / den : -((-num) / den);
+}
+__device__ __forceinline__ int floor_div_any(int num, int den) {
+  return (num >= 0) ? num / den : -((-num + den - 1) / den);
+}
+
+__global__ void __launch_bounds__(256) correlation_grad_kernel(
+    const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b,
+    float* __restrict__ da, float* __restrict__ db, int N, int H, int W, int C, int k, int md, int s1,
+    int s2, int pad, int oh, int ow, int gr, int gw) {
+  const int kr = (k - 1) / 2;
+  const int D = gw * gw;
+  const long total = (long)N * H * W * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int xx = (int)((idx / C) % W);
+    const int yy = (int)((idx / C / W) % H);
+    const int n = (int)(idx / C / W / H);
+    const int x = xx + pad, y = yy + pad;  // padded coordinates, :44-45
+    float sa = 0.f, sb = 0.f;
+    // ranges for grad A do not depend on the displacement (:51-72)
+    int axmin = ceil_div_any(x - 2 * kr - md, s1), aymin = ceil_div_any(y - 2 * kr - md, s1);
+    int axmax = floor_div_any(x - md, s1), aymax = floor_div_any(y - md, s1);
+    const bool a_ok = (axmax >= 0) && (aymax >= 0) && (axmin <= ow - 1) && (aymin <= oh - 1);
+    axmin = max(0, axmin); axmax = min(ow - 1, axmax);
+    aymin = max(0, aymin); aymax = min(oh - 1, aymax);
+    for (int p = -gr; p <= gr; ++p) {
+      for (int o = -gr; o <= gr; ++o) {
+        const int s2o = s2 * o, s2p = s2 * p;
+        const int op = (p + gr) * gw + (o + gr);
+        if (a_ok) {
+          const int yb = y + s2p - pad, xb = x + s2o - pad;  // B0 read, zero outside the image
+          if (yb >= 0 && yb < H && xb >= 0 && xb < W) {
+            const float bv = b[(((long)n * H + yb) * W + xb) * C + c];
+            float gs = 0.f;
+            for (int y2 = aymin; y2 <= aymax; ++y2)
+              for (int x2 = axmin; x2 <= axmax; ++x2) gs += g[(((long)n * oh + y2) * ow + x2) * D + op];
+            sa += gs * bv;
+          }
+        }
+        int bxmin = ceil_div_any(x - 2 * kr - md - s2o, s1), bymin = ceil_div_any(y - 2 * kr - md - s2p, s1);
+        int bxmax = floor_div_any(x - md - s2o, s1), bymax = floor_div_any(y - md - s2p, s1);
+        if ((bxmax >= 0) && (bymax >= 0) && (bxmin <= ow - 1) && (bymin <= oh - 1)) {
+          bxmin = max(0, bxmin); bxmax = min(ow - 1, bxmax);
+          bymin = max(0, bymin); bymax = min(oh - 1, bymax);
+          const int ya = y - s2p - pad, xa = x - s2o - pad;  // A0 read (:165-168)
+          if (ya >= 0 && ya < H && xa >= 0 && xa < W) {
+            const float av = a[(((long)n * H + ya) * W + xa) * C + c];
+            float gs = 0.f;
+            for (int y2 = bymin; y2 <= bymax; ++y2)
+              for (int x2 = bxmin; x2 <= bxmax; ++x2) gs += g[(((long)n * oh + y2) * ow + x2) * D + op];
+            sb += gs * av;
+          }
+        }
+      }
+    }
+    const float sumelems = (float)((2 * kr + 1) * (2 * kr + 1) * C);
+    da[idx] = sa / sumelems;
+    db[idx] = sb / sumelems;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// flow_warp (flow_warp.cu.cc:44-95): one lane per pixel, all channels in the lane.
+// ---------------------------------------------------------------------------
+struct WarpTaps {
+  bool valid;
+  int xL, xR, yT, yB;
+  float cTL, cTR, cBL, cBR, alpha, beta, x2, y2;
+};
+__device__ __forceinline__ WarpTaps warp_taps(int x, int y, float u, float v, int W, int H) {
+  WarpTaps t;
+  t.x2 = (float)x + u;  // :45
+  t.y2 = (float)y + v;  // :46
+  t.valid = (t.x2 >= 0.f) && (t.y2 >= 0.f) && (t.x2 < (float)W) && (t.y2 < (float)H);  // NaN fails, :80
+  const float xs = t.valid ? t.x2 : 0.f, ys = t.valid ? t.y2 : 0.f;
+  t.xL = (int)xs;  // truncation, :54
+  t.yT = (int)ys;
+  t.xR = min(t.xL + 1, W - 1);  // :56
+  t.yB = min(t.yT + 1, H - 1);
+  t.alpha = xs - (float)t.xL;  // :64
+  t.beta = ys - (float)t.yT;
+  t.cTL = (1.f - t.alpha) * (1.f - t.beta);  // :66-69
+  t.cTR = t.alpha * (1.f - t.beta);
+  t.cBL = (1.f - t.alpha) * t.beta;
+  t.cBR = t.alpha * t.beta;
+  return t;
+}
+
+template <int CFIX>
+__global__ void __launch_bounds__(256) flow_warp_kernel(const float* __restrict__ image,
+                                                        const float* __restrict__ flow,
+                                                        float* __restrict__ out, int N, int H, int W, int C) {
+  const long npix = (long)N * H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix;
+       pix += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const long nb = (pix / W / H) * (long)H * W;
+    const float2 f = *reinterpret_cast<const float2*>(flow + pix * 2);
+    const WarpTaps t = warp_taps(x, y, f.x, f.y, W, H);
+    const int CC = CFIX > 0 ? CFIX : C;
+    const float* pTL = image + (nb + (long)t.yT * W + t.xL) * CC;
+    const float* pTR = image + (nb + (long)t.yT * W + t.xR) * CC;
+    const float* pBL = image + (nb + (long)t.yB * W + t.xL) * CC;
+    const float* pBR = image + (nb + (long)t.yB * W + t.xR) * CC;
+    float* po = out + pix * CC;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      float v = 0.f;
+      if (t.valid) v = t.cTL * pTL[c] + t.cTR * pTR[c] + t.cBL * pBL[c] + t.cBR * pBR[c];  // :82-86
+      po[c] = v;
+    }
+  }
+}
+
+// flow_warp backward (flow_warp_grad.cu.cc:30-86).  image_grad must be zeroed by the caller
+// (hipMemsetAsync on the same stream in the launcher); flow_grad is written for every pixel.
+__global__ void __launch_bounds__(256) flow_warp_grad_kernel(const float* __restrict__ image,
+                                                             const float* __restrict__ flow,
+                                                             const float* __restrict__ grad,
+                                                             float* __restrict__ image_grad,
+                                                             float* __restrict__ flow_grad, int N, int H,
+                                                             int W, int C) {
+  const long npix = (long)N * H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix;
+       pix += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const long nb = (pix / W / H) * (long)H * W;
+    const float2 f = *reinterpret_cast<const float2*>(flow + pix * 2);
+    const WarpTaps t = warp_taps(x, y, f.x, f.y, W, H);
+    float du = 0.f, dv = 0.f;
+    if (t.valid) {
+      const long oTL = (nb + (long)t.yT * W + t.xL) * C, oTR = (nb + (long)t.yT * W + t.xR) * C;
+      const long oBL = (nb + (long)t.yB * W + t.xL) * C, oBR = (nb + (long)t.yB * W + t.xR) * C;
+      const float gy = (float)t.yB - t.y2;  // gamma = iy2_B - y2, :54
+      const float gx = (float)t.xR - t.x2;  // gamma = ix2_R - x2, :71
+      for (int c = 0; c < C; ++c) {
+        const float g = grad[pix * C + c];
+        atomicAdd(image_grad + oTL + c, g * t.cTL);  // :43-52
+        atomicAdd(image_grad + oTR + c, g * t.cTR);
+        atomicAdd(image_grad + oBL + c, g * t.cBL);
+        atomicAdd(image_grad + oBR + c, g * t.cBR);
+        const float TL = image[oTL + c], TR = image[oTR + c], BL = image[oBL + c], BR = image[oBR + c];
+        du += g * (gy * (TR - TL) + (1.f - gy) * (BR - BL));  // :57-69
+        dv += g * (gx * (BL - TL) + (1.f - gx) * (BR - TR));  // :74-85
+      }
+    }
+    *reinterpret_cast<float2*>(flow_grad + pix * 2) = make_float2(du, dv);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// downsample (downsample_kernel_gpu.cu.cc:35-76): one wavefront per output
+// pixel (all channels, C <= 4 per pass), lanes stride the tap window, wave64
+// shuffle reduction of the three accumulators.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) downsample_kernel(const float* __restrict__ in,
+                                                         float* __restrict__ out, int N, int Hin, int Win,
+                                                         int C, int oh, int ow, float wscale, float hscale,
+                                                         int wr, int hr) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const long nout = (long)N * oh * ow;
+  for (long o = wave; o < nout; o += nwaves) {
+    const int dx = (int)(o % ow);
+    const int dy = (int)((o / ow) % oh);
+    const int n = (int)(o / ow / oh);
+    const float srcx = ((float)dx / (float)(ow - 1)) * (float)(Win - 1);  // :41
+    const float srcy = ((float)dy / (float)(oh - 1)) * (float)(Hin - 1);  // :42
+    const int ix = (int)roundf(srcx), iy = (int)roundf(srcy);             // :44-45
+    const int ww = 2 * wr + 1, wh = 2 * hr + 1;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float av[4] = {0, 0, 0, 0}, aw[4] = {0, 0, 0, 0}, an[4] = {0, 0, 0, 0};
+      for (int t = lane; t < ww * wh; t += 64) {
+        const int xo = ix - wr + t % ww, yo = iy - hr + t / ww;
+        if (xo >= 0 && yo >= 0 && xo < Win && yo < Hin) {
+          const float wgt = fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale) *
+                            fmaxf(0.f, 1.f - fabsf((float)yo - srcy) / hscale);  // :57-58
+          const float* p = in + (((long)n * Hin + yo) * Win + xo) * C + c0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c0 + c < C) {
+              const float s = p[c];
+              if (s != s) {  // NaN sample: counts as NaN weight only, :59-63
+                an[c] += wgt;
+              } else {
+                av[c] += s * wgt;
+                aw[c] += wgt;
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v = wave_sum(av[c]), w = wave_sum(aw[c]), nn = wave_sum(an[c]);
+        if (lane == 0 && c0 + c < C)
+          out[o * C + c0 + c] = (nn / w > 0.5f) ? __int_as_float(0x7fffffff) : v / w;  // :68-72
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// resize_bilinear(align_corners=True) of scale*in (flownet_s.py:107-111)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __restrict__ in,
+                                                              float* __restrict__ out, int N, int Hin,
+                                                              int Win, int C, int oh, int ow, float sy,
+                                                              float sx, float scale) {
+  const long total = (long)N * oh * ow;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(o % ow);
+    const int y = (int)((o / ow) % oh);
+    const int n = (int)(o / ow / oh);
+    const float fy = (float)y * sy, fx = (float)x * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* b = in + (long)n * Hin * Win * C;
+    for (int c = 0; c < C; ++c) {
+      const float tl = b[((long)y0 * Win + x0) * C + c], tr = b[((long)y0 * Win + x1) * C + c];
+      const float bl = b[((long)y1 * Win + x0) * C + c], br = b[((long)y1 * Win + x1) * C + c];
+      const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
+      out[o * C + c] = (top + (bot - top) * ly) * scale;
+    }
+  }
+}
+
+static inline int grid_for(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 256L * 16) g = 256L * 16;  // 256 CUs x 16 blocks, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int correlation_geometry(int h, int w, int k, int md, int s1, int s2, int pad, int* oh, int* ow, int* gr,
+                         int* gw) {
+  FN2_REQUIRE(k > 0 && (k % 2) != 0, "kernel_size must be odd");  // correlation_kernel.cc:23
+  FN2_REQUIRE(md >= 0 && s1 >= 1 && s2 >= 1 && pad >= 0, "correlation: bad attributes");
+  const int kr = (k - 1) / 2, border = md + kr;
+  const int hp = h + 2 * pad, wp = w + 2 * pad;
+  *oh = (int)ceilf((float)(hp - border * 2) / (float)s1);  // :50
+  *ow = (int)ceilf((float)(wp - border * 2) / (float)s1);  // :51
+  FN2_REQUIRE(*oh >= 1, "Neighborhood and kernel don't fit in input height.");  // :53
+  FN2_REQUIRE(*ow >= 1, "Neighborhood and kernel don't fit in input width.");   // :55
+  *gr = md / s2;
+  *gw = 2 * (*gr) + 1;
+  // The reference never bounds-checks the displaced read; outside pad >= gr*s2 - ... it is UB.
+  const int lo = md - (*gr) * s2;
+  const int hiy = (*oh - 1) * s1 + md + (*gr) * s2 + k - 1, hix = (*ow - 1) * s1 + md + (*gr) * s2 + k - 1;
+  FN2_REQUIRE(lo >= 0 && hiy < hp && hix < wp,
+              "displacement window leaves the padded input (undefined in the reference)");
+  return FN2_OK;
+}
+
+}  // namespace fn2
+
+using namespace fn2;
+
+extern "C" {
+
+const char* fn2_last_error(void) { return fn2::err_buf(); }
+int fn2_version(void) { return 1; }
+
+int fn2_device_info(char* name, int cap, int* cus) {
+  int dev = 0;
+  FN2_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  FN2_HIP(hipGetDeviceProperties(&p, dev));
+  if (name && cap > 0) snprintf(name, cap, "%s", p.gcnArchName);
+  if (cus) *cus = p.multiProcessorCount;
+  return FN2_OK;
+}
+
+int fn2_correlation_out_shape(int h, int w, int k, int md, int s1, int s2, int pad, int* oh, int* ow,
+                              int* oc) {
+  int gr, gw;
+  int rc = correlation_geometry(h, w, k, md, s1, s2, pad, oh, ow, &gr, &gw);
+  if (rc) return rc;
+  *oc = gw * gw;
+  return FN2_OK;
+}
+
+int fn2_correlation_generic_f32(const float* a, const float* b, float* out, int n, int h, int w, int c,
+                                int k, int md, int s1, int s2, int pad, void* stream) {
+  FN2_REQUIRE(a && b && out, "correlation: null pointer");
+  FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "correlation: inputs must have rank 4 with positive dims");
+  int oh, ow, gr, gw;
+  int rc = correlation_geometry(h, w, k, md, s1, s2, pad, &oh, &ow, &gr, &gw);
+  if (rc) return rc;
+  const long total = (long)n * oh * ow * gw * gw;
+  hipLaunchKernelGGL(correlation_generic_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, out, n, h, w, c, k, md, s1, s2, pad, oh, ow, gr, gw);
+  FN2_CHECK_LAUNCH("correlation_generic");
+  return FN2_OK;
+}
+
+int fn2_correlation_grad_f32(const float* g, const float* a, const float* b, float* da, float* db, int n,
+                             int h, int w, int c, int k, int md, int s1, int s2, int pad, void* stream) {
+  FN2_REQUIRE(g && a && b && da && db, "correlation_grad: null pointer");
+  FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "correlation_grad: bad dims");
+  int oh, ow, gr, gw;
+  int rc = correlation_geometry(h, w, k, md, s1, s2, pad, &oh, &ow, &gr, &gw);
+  if (rc) return rc;
+  const long total = (long)n * h * w * c;
+  hipLaunchKernelGGL(correlation_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     g, a, b, da, db, n, h, w, c, k, md, s1, s2, pad, oh, ow, gr, gw);
+  FN2_CHECK_LAUNCH("correlation_grad");
+  return FN2_OK;
+}
+
+int fn2_flow_warp_f32(const float* image, const float* flow, float* out, int n, int h, int w, int c,
+                      void* stream) {
+  FN2_REQUIRE(image && flow && out, "flow_warp: null pointer");
+  FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "Input images must have rank 4");  // flow_warp.cc:22
+  const long npix = (long)n * h * w;
+  if (c == 3)
+    hipLaunchKernelGGL(flow_warp_kernel<3>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, image,
+                       flow, out, n, h, w, c);
+  else
+    hipLaunchKernelGGL(flow_warp_kernel<0>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, image,
+                       flow, out, n, h, w, c);
+  FN2_CHECK_LAUNCH("flow_warp");
+  return FN2_OK;
+}
+
+int fn2_flow_warp_grad_f32(const float* image, const float* flow, const float* grad, float* image_grad,
+                           float* flow_grad, int n, int h, int w, int c, void* stream) {
+  FN2_REQUIRE(image && flow && grad && image_grad && flow_grad, "flow_warp_grad: null pointer");
+  FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "flow_warp_grad: bad dims");
+  const long npix = (long)n * h * w;
+  FN2_HIP(hipMemsetAsync(image_grad, 0, sizeof(float) * npix * c, (hipStream_t)stream));  // same stream
+  hipLaunchKernelGGL(flow_warp_grad_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, image,
+                     flow, grad, image_grad, flow_grad, n, h, w, c);
+  FN2_CHECK_LAUNCH("flow_warp_grad");
+  return FN2_OK;
+}
+
+int fn2_downsample_f32(const float* in, float* out, int n, int in_h, int in_w, int c, int out_h, int out_w,
+                       void* stream) {
+  FN2_REQUIRE(in && out, "downsample: null pointer");
+  FN2_REQUIRE(n >= 1 && in_h >= 1 && in_w >= 1 && c >= 1, "Input images must have rank 4");  // downsample_kernel.cc:25
+  FN2_REQUIRE(out_h >= 1 && out_w >= 1, "downsample: size must be positive");
+  const float wscale = (float)(in_w - 1) / (float)(out_w - 1);  // :92 (division by zero not guarded, as the reference)
+  const float hscale = (float)(in_h - 1) / (float)(out_h - 1);
+  FN2_REQUIRE(out_h > 1 && out_w > 1, "downsample: output size 1 divides by zero in the reference kernel");
+  const int wr = (int)ceilf(wscale), hr = (int)ceilf(hscale);
+  const long nout = (long)n * out_h * out_w;
+  hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(nout * 64, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, n, in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr);
+  FN2_CHECK_LAUNCH("downsample");
+  return FN2_OK;
+}
+
+int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in_w, int c, int out_h,
+                            int out_w, float scale, void* stream) {
+  FN2_REQUIRE(in && out, "resize_bilinear: null pointer");
+  FN2_REQUIRE(n >= 1 && in_h >= 1 && in_w >= 1 && c >= 1 && out_h >= 1 && out_w >= 1, "resize_bilinear: bad dims");
+  const float sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
+  const float sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
+  const long total = (long)n * out_h * out_w;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, n, in_h, in_w, c, out_h, out_w, sy, sx, scale);
+  FN2_CHECK_LAUNCH("resize_bilinear");
+  return FN2_OK;
+}
+
+int fn2_capture_begin(void* stream) {
+  FN2_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return FN2_OK;
+}
+int fn2_capture_end(void* stream, void** graph_exec) {
+  hipGraph_t g = nullptr;
+  FN2_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return fn2::fail(FN2_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  *graph_exec = (void*)ge;
+  return FN2_OK;
+}
+int fn2_graph_launch(void* graph_exec, void* stream) {
+  FN2_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return FN2_OK;
+}
+int fn2_graph_destroy(void* graph_exec) {
+  FN2_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return FN2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+"""Static-plan executor for FlowNetS / C / SD / CS / CSS / 2 on one MI355X.
+
+What the reference builds as a TF1 graph and runs through ``sess.run``
+(src/net.py:542-570) is here a flat list of C-ABI calls into libflownet2_hip.so
+over preallocated NHWC activation buffers:
+
+  * every conv / transposed conv is one fn2_conv2d launch (implicit GEMM on MFMA)
+    with zero-pad, bias, LeakyReLU and the concat fused: a layer writes straight
+    into its channel slice of the consumer's concat buffer, so tf.concat, tf.pad,
+    antipad and the 4-node LeakyReLU never exist as kernels;
+  * correlation (+LeakyReLU, + write into the 473-channel concat), flow_warp +
+    brightness error + 12-channel stack, the FlowNet2 fusion input, upsample_flow
+    and the final resize are single fused HBM-bound kernels;
+  * the plan can be captured once into a hipGraph (``capture()``) and replayed.
+
+torch is only the device-memory container (buffers, streams).  dtype "f32" runs
+the fp32 MFMA parity path, "bf16" the bf16 MFMA throughput path (activations and
+weights bf16, fp32 accumulate, flow heads / warps / resize in fp32).
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip, netdefs, weights as W
+
+_DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Engine:
+    def __init__(self, model, weights, batch, height, width, dtype="f32", device=None):
+        if model not in netdefs.MODELS:
+            raise ValueError("unknown model %r" % model)
+        if dtype not in _DT:
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if height % 64 or width % 64:
+            raise ValueError("height and width must be multiples of 64 (pad with Net.adapt_x, net.py:373-388)")
+        self.lib = _hip.lib()
+        self.device = device if device is not None else _hip.require_device()
+        self.model, self.N, self.H, self.W = model, int(batch), int(height), int(width)
+        self.dtype_name, self.tdtype = dtype, _DT[dtype]
+        self.kstep = 32 if dtype == "bf16" else 16
+        self.weights = weights
+        self.ops = []      # (name, fn, args) ; args exclude the trailing stream
+        self.keep = []     # keep ctypes structs / tensors alive
+        self.bufs = {}
+        self.layer_flops = []  # (name, flop) algorithmic, for roofline accounting
+        self.in_a = torch.zeros((self.N, self.H, self.W, 3), dtype=torch.float32, device=self.device)
+        self.in_b = torch.zeros_like(self.in_a)
+        self.graph = None
+        self.outputs = self._build()
+
+    # ------------------------------------------------------------------ buffers / views
+    def _buf(self, name, n, h, w, c, dtype=None):
+        cs = _round_up(c, 8) if dtype is None else c
+        t = torch.zeros((n, h, w, cs), dtype=self.tdtype if dtype is None else dtype, device=self.device)
+        assert name not in self.bufs, name
+        self.bufs[name] = t
+        return t
+
+    @staticmethod
+    def _v(buf, c=None, c0=0):
+        return _hip.view(buf, c, c0)
+
+    def _op(self, name, fn, *args):
+        self.ops.append((name, fn, args))
+
+    # ------------------------------------------------------------------ layers
+    def _conv(self, scope, spec, src, dst):
+        """src/dst: (buffer, c0, c).  One fn2_conv2d launch."""
+        name, kind, k, stride, pad, cin, cout, act = spec
+        sbuf, sc0, sc = src
+        dbuf, dc0, dc = dst
+        assert sc == cin and dc == cout, (scope, name, sc, cin, dc, cout)
+        tile = self.lib.fn2_conv2d_cout_tile(cout)
+        wname = f"{scope}/{name}/weights"
+        if kind == "conv":
+            packed, cin_pad, cout_pad, kpad = W.pack_conv(self.weights[wname], tile, self.kstep)
+            bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
+        else:
+            packed, cin_pad, cout_pad, kpad = W.pack_deconv(self.weights[wname], tile, self.kstep)
+            bias = None
+        wdev = W.to_device(packed, self.tdtype, self.device)
+        d = _hip.Fn2ConvDesc()
+        d.inp = self._v(sbuf, sc, sc0)
+        d.out = self._v(dbuf, dc, dc0)
+        d.wgt = wdev.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.kind = 0 if kind == "conv" else 1
+        d.kh = d.kw = k
+        d.stride, d.pad = stride, pad
+        d.act = _hip.ACT_LEAKY if act else _hip.ACT_NONE
+        d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
+        self.keep += [d, wdev, bias]
+        self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d))
+        n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
+        taps = k * k if kind == "conv" else 4
+        self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * taps * cin * cout))
+
+    def _upflow(self, scope, name, src_f32, dst):
+        dbuf, dc0, dc = dst
+        w = W.to_device(self.weights[f"{scope}/{name}/weights"], torch.float32, self.device)  # [4,4,2,2] HW-O-I
+        v = self._v(dbuf, dc, dc0)
+        self.keep += [w, v]
+        n, h, wd, _ = src_f32.shape
+        self._op(f"{scope}/{name}", self.lib.fn2_upsample_flow, _hip.ptr(src_f32), _hip.ptr(w), C.byref(v), n, h, wd)
+
+    def _resize(self, name, src_f32, scale):
+        n, h, w, c = src_f32.shape
+        dst = self._buf(name, n, self.H, self.W, 2, torch.float32)
+        self._op(name, self.lib.fn2_resize_bilinear_f32, _hip.ptr(src_f32), _hip.ptr(dst), n, h, w, c, self.H,
+                 self.W, C.c_float(scale))
+        return dst
+
+    # ------------------------------------------------------------------ sub-networks
+    def _refine(self, scope, tag, L, c6_1, cats, interconv):
+        """4-level decoder (flownet_s.py:52-104; flownet_sd.py:45-103)."""
+        N = c6_1.shape[0]
+        preds = {}
+        h, w = c6_1.shape[1], c6_1.shape[2]
+        pf = self._buf(f"{tag}/predict_flow6", N, h, w, 2, torch.float32)
+        self._conv(scope, L["predict_flow6"], (c6_1, 0, 1024), (pf, 0, 2))
+        preds["predict_flow6"] = pf
+        cur, cur_c = c6_1, 1024
+        for lvl, skip_c, dec_c in zip((5, 4, 3, 2), (512, 512, 256, 128), (512, 256, 128, 64)):
+            cat = cats[lvl]
+            h, w = cat.shape[1], cat.shape[2]
+            self._conv(scope, L[f"deconv{lvl}"], (cur, 0, cur_c), (cat, skip_c, dec_c))
+            self._upflow(scope, f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2))
+            cur, cur_c = cat, skip_c + dec_c + 2
+            head_src = (cat, 0, cur_c)
+            if interconv:
+                ic = self._buf(f"{tag}/interconv{lvl}", N, h, w, dec_c)
+                self._conv(scope, L[f"interconv{lvl}"], (cat, 0, cur_c), (ic, 0, dec_c))
+                head_src = (ic, 0, dec_c)
+            pf = self._buf(f"{tag}/predict_flow{lvl}", N, h, w, 2, torch.float32)
+            self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2))
+            preds[f"predict_flow{lvl}"] = pf
+        return preds
+
+    def _alloc_cats(self, tag, N):
+        H, W_ = self.H, self.W
+        return {5: self._buf(f"{tag}/concat5", N, H // 32, W_ // 32, 1026),
+                4: self._buf(f"{tag}/concat4", N, H // 16, W_ // 16, 770),
+                3: self._buf(f"{tag}/concat3", N, H // 8, W_ // 8, 386),
+                2: self._buf(f"{tag}/concat2", N, H // 4, W_ // 4, 194)}
+
+    def _encoder_tail(self, scope, tag, L, cats):
+        """conv4 .. conv6_1 from conv3_1 (already in concat3[0:256]); skips land in the concat buffers."""
+        N, H, W_ = self.N, self.H, self.W
+        c4 = self._buf(f"{tag}/conv4", N, H // 16, W_ // 16, 512)
+        self._conv(scope, L["conv4"], (cats[3], 0, 256), (c4, 0, 512))
+        self._conv(scope, L["conv4_1"], (c4, 0, 512), (cats[4], 0, 512))
+        c5 = self._buf(f"{tag}/conv5", N, H // 32, W_ // 32, 512)
+        self._conv(scope, L["conv5"], (cats[4], 0, 512), (c5, 0, 512))
+        self._conv(scope, L["conv5_1"], (c5, 0, 512), (cats[5], 0, 512))
+        c6 = self._buf(f"{tag}/conv6", N, H // 64, W_ // 64, 1024)
+        self._conv(scope, L["conv6"], (cats[5], 0, 512), (c6, 0, 1024))
+        c6_1 = self._buf(f"{tag}/conv6_1", N, H // 64, W_ // 64, 1024)
+        self._conv(scope, L["conv6_1"], (c6, 0, 1024), (c6_1, 0, 1024))
+        return c6_1
+
+    def _net_s(self, scope, tag, x, cin):
+        """FlowNetS.model (flownet_s.py:14-120) on the packed input x (6 or 12 channels)."""
+        N, H, W_ = self.N, self.H, self.W
+        L = {s[0]: s for s in netdefs.flownet_s_layers(cin)}
+        cats = self._alloc_cats(tag, N)
+        c1 = self._buf(f"{tag}/conv1", N, H // 2, W_ // 2, 64)
+        self._conv(scope, L["conv1"], (x, 0, cin), (c1, 0, 64))
+        self._conv(scope, L["conv2"], (c1, 0, 64), (cats[2], 0, 128))
+        c3 = self._buf(f"{tag}/conv3", N, H // 8, W_ // 8, 256)
+        self._conv(scope, L["conv3"], (cats[2], 0, 128), (c3, 0, 256))
+        self._conv(scope, L["conv3_1"], (c3, 0, 256), (cats[3], 0, 256))
+        c6_1 = self._encoder_tail(scope, tag, L, cats)
+        preds = self._refine(scope, tag, L, c6_1, cats, False)
+        preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], 20.0)  # flownet_s.py:107-111
+        return preds
+
+    def _net_c(self, scope, tag):
+        """FlowNetC.model (flownet_c.py:15-125).  conv1 of both towers is one 2N-batch launch."""
+        N, H, W_ = self.N, self.H, self.W
+        L = {s[0]: s for s in netdefs.flownet_c_layers()}
+        cats = self._alloc_cats(tag, N)
+        x2 = self._buf(f"{tag}/images", 2 * N, H, W_, 3)
+        v = self._v(x2, 3, 0)
+        self.keep.append(v)
+        self._op(f"{tag}/pack_a", self.lib.fn2_pack_image, _hip.ptr(self.in_a), N, C.byref(v), 0)
+        self._op(f"{tag}/pack_b", self.lib.fn2_pack_image, _hip.ptr(self.in_b), N, C.byref(v), N)
+        c1 = self._buf(f"{tag}/conv1", 2 * N, H // 2, W_ // 2, 64)
+        self._conv(scope, L["conv1"], (x2, 0, 3), (c1, 0, 64))
+        c2b = self._buf(f"{tag}/conv_b_2", N, H // 4, W_ // 4, 128)
+        self._conv(scope, L["conv2"], (c1[:N], 0, 64), (cats[2], 0, 128))  # conv_a_2 = the level-2 skip, :105
+        self._conv(scope, L["conv2"], (c1[N:], 0, 64), (c2b, 0, 128))
+        c3a = self._buf(f"{tag}/conv_a_3", N, H // 8, W_ // 8, 256)
+        c3b = self._buf(f"{tag}/conv_b_3", N, H // 8, W_ // 8, 256)
+        self._conv(scope, L["conv3"], (cats[2], 0, 128), (c3a, 0, 256))
+        self._conv(scope, L["conv3"], (c2b, 0, 128), (c3b, 0, 256))
+        net = self._buf(f"{tag}/corr_concat", N, H // 8, W_ // 8, 473)  # [conv_redir(32) | corr(441)], :46
+        va, vb, vo = self._v(c3a, 256, 0), self._v(c3b, 256, 0), self._v(net, 441, 32)
+        self.keep += [va, vb, vo]
+        self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
+                 _hip.ACT_LEAKY)  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
+        self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
+        self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
+        self._conv(scope, L["conv3_1"], (net, 0, 473), (cats[3], 0, 256))
+        c6_1 = self._encoder_tail(scope, tag, L, cats)
+        preds = self._refine(scope, tag, L, c6_1, cats, False)
+        preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], 20.0)  # flownet_c.py:112-116
+        return preds
+
+    def _net_sd(self, scope, tag, x):
+        """FlowNetSD.model (flownet_sd.py:14-119)."""
+        N, H, W_ = self.N, self.H, self.W
+        L = {s[0]: s for s in netdefs.flownet_sd_layers()}
+        cats = self._alloc_cats(tag, N)
+        c0 = self._buf(f"{tag}/conv0", N, H, W_, 64)
+        self._conv(scope, L["conv0"], (x, 0, 6), (c0, 0, 64))
+        c1 = self._buf(f"{tag}/conv1", N, H // 2, W_ // 2, 64)
+        self._conv(scope, L["conv1"], (c0, 0, 64), (c1, 0, 64))
+        c1_1 = self._buf(f"{tag}/conv1_1", N, H // 2, W_ // 2, 128)
+        self._conv(scope, L["conv1_1"], (c1, 0, 64), (c1_1, 0, 128))
+        self._conv(scope, L["conv2"], (c1_1, 0, 128), (cats[2], 0, 128))  # skip = conv2, :97
+        c2_1 = self._buf(f"{tag}/conv2_1", N, H // 4, W_ // 4, 128)
+        self._conv(scope, L["conv2_1"], (cats[2], 0, 128), (c2_1, 0, 128))
+        c3 = self._buf(f"{tag}/conv3", N, H // 8, W_ // 8, 256)
+        self._conv(scope, L["conv3"], (c2_1, 0, 128), (c3, 0, 256))
+        self._conv(scope, L["conv3_1"], (c3, 0, 256), (cats[3], 0, 256))
+        c6_1 = self._encoder_tail(scope, tag, L, cats)
+        preds = self._refine(scope, tag, L, c6_1, cats, True)
+        preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], 0.05)  # flownet_sd.py:106-110
+        return preds
+
+    def _pair_input(self, tag):
+        x = self._buf(f"{tag}/pair", self.N, self.H, self.W, 6)
+        v = self._v(x, 6, 0)
+        self.keep.append(v)
+        self._op(f"{tag}/pack_pair", self.lib.fn2_pack_pair, _hip.ptr(self.in_a), _hip.ptr(self.in_b), C.byref(v))
+        return x
+
+    def _stacked_input(self, tag, flow):
+        x = self._buf(f"{tag}/stack", self.N, self.H, self.W, 16)
+        v = self._v(x, 12, 0)
+        self.keep.append(v)
+        self._op(f"{tag}/stack_input", self.lib.fn2_stack_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
+                 _hip.ptr(flow), C.byref(v))  # flow_warp + brightness error + concat, flownet_cs.py:21-36
+        return x
+
+    def _net_cs(self, scope, tag):
+        pc = self._net_c(scope + "/FlowNetC", tag + "/C")
+        return self._net_s(scope + "/FlowNetS", tag + "/S", self._stacked_input(tag + "/S", pc["flow"]), 12)
+
+    def _net_css(self, scope, tag):
+        pcs = self._net_cs(scope + "/FlowNetCS", tag + "/CS")
+        return self._net_s(scope + "/FlowNetS", tag + "/S", self._stacked_input(tag + "/S", pcs["flow"]), 12)
+
+    def _net_2(self, scope, tag):
+        """FlowNet2.model (flownet2.py:18-105)."""
+        N, H, W_ = self.N, self.H, self.W
+        css = self._net_css(scope + "/FlowNetCSS", tag + "/CSS")
+        sd = self._net_sd(scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD"))
+        L = {s[0]: s for s in netdefs.fusion_layers()}
+        xf = self._buf(f"{tag}/fusion_in", N, H, W_, 16)
+        v = self._v(xf, 11, 0)
+        self.keep.append(v)
+        self._op(f"{tag}/fusion_input", self.lib.fn2_fusion_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
+                 _hip.ptr(sd["flow"]), _hip.ptr(css["flow"]), C.byref(v))
+        cat0 = self._buf(f"{tag}/concat0", N, H, W_, 82)
+        cat1 = self._buf(f"{tag}/concat1", N, H // 2, W_ // 2, 162)
+        self._conv(scope, L["fuse_conv0"], (xf, 0, 11), (cat0, 0, 64))
+        f1 = self._buf(f"{tag}/fuse_conv1", N, H // 2, W_ // 2, 64)
+        self._conv(scope, L["fuse_conv1"], (cat0, 0, 64), (f1, 0, 64))
+        self._conv(scope, L["fuse_conv1_1"], (f1, 0, 64), (cat1, 0, 128))
+        f2 = self._buf(f"{tag}/fuse_conv2", N, H // 4, W_ // 4, 128)
+        self._conv(scope, L["fuse_conv2"], (cat1, 0, 128), (f2, 0, 128))
+        f2_1 = self._buf(f"{tag}/fuse_conv2_1", N, H // 4, W_ // 4, 128)
+        self._conv(scope, L["fuse_conv2_1"], (f2, 0, 128), (f2_1, 0, 128))
+        pf2 = self._buf(f"{tag}/predict_flow2", N, H // 4, W_ // 4, 2, torch.float32)
+        self._conv(scope, L["predict_flow2"], (f2_1, 0, 128), (pf2, 0, 2))
+        self._conv(scope, L["fuse_deconv1"], (f2_1, 0, 128), (cat1, 128, 32))
+        self._upflow(scope, "fuse_upsample_flow2to1", pf2, (cat1, 160, 2))
+        ic1 = self._buf(f"{tag}/fuse_interconv1", N, H // 2, W_ // 2, 32)
+        self._conv(scope, L["fuse_interconv1"], (cat1, 0, 162), (ic1, 0, 32))
+        pf1 = self._buf(f"{tag}/predict_flow1", N, H // 2, W_ // 2, 2, torch.float32)
+        self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2))
+        self._conv(scope, L["fuse_deconv0"], (cat1, 0, 162), (cat0, 64, 16))
+        self._upflow(scope, "fuse_upsample_flow1to0", pf1, (cat0, 80, 2))
+        ic0 = self._buf(f"{tag}/fuse_interconv0", N, H, W_, 16)
+        self._conv(scope, L["fuse_interconv0"], (cat0, 0, 82), (ic0, 0, 16))
+        pf0 = self._buf(f"{tag}/predict_flow0", N, H, W_, 2, torch.float32)
+        self._conv(scope, L["predict_flow0"], (ic0, 0, 16), (pf0, 0, 2))
+        # resize_bilinear to (height, width) of a full-resolution tensor is the identity (flownet2.py:100-101)
+        return {"predict_flow0": pf0, "flow": pf0}
+
+    def _build(self):
+        m = self.model
+        if m == "FlowNetS":
+            return self._net_s("FlowNetS", "S", self._pair_input("S"), 6)
+        if m == "FlowNetC":
+            return self._net_c("FlowNetC", "C")
+        if m == "FlowNetSD":
+            return self._net_sd("FlowNetSD", "SD", self._pair_input("SD"))
+        if m == "FlowNetCS":
+            return self._net_cs("FlowNetCS", "CS")
+        if m == "FlowNetCSS":
+            return self._net_css("FlowNetCSS", "CSS")
+        return self._net_2("FlowNet2", "F2")
+
+    # ------------------------------------------------------------------ execution
+    def set_inputs(self, input_a, input_b):
+        """input_a/b: [N,H,W,3] float32 in [0,1] (torch, any device, or numpy)."""
+        for dst, src in ((self.in_a, input_a), (self.in_b, input_b)):
+            t = src if isinstance(src, torch.Tensor) else torch.as_tensor(src)
+            if tuple(t.shape) != tuple(dst.shape):
+                raise ValueError("input shape %s != engine shape %s" % (tuple(t.shape), tuple(dst.shape)))
+            dst.copy_(t.to(dtype=torch.float32), non_blocking=True)
+
+    def launch(self):
+        """Enqueue one forward pass on torch's current stream (no host sync)."""
+        if self.graph is not None:
+            _hip.check(self.lib.fn2_graph_launch(self.graph, _hip.stream_ptr()))
+            return
+        s = _hip.stream_ptr()
+        for name, fn, args in self.ops:
+            rc = fn(*args, s)
+            if rc:
+                try:
+                    _hip.check(rc)
+                except Exception as e:
+                    raise type(e)("%s: %s" % (name, e)) from None
+
+    def capture(self):
+        """Record the plan into a hipGraph on a side stream; later launch() calls replay it."""
+        if self.graph is not None:
+            return
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.launch()  # warm: module load, first-touch
+            side.synchronize()
+            _hip.check(self.lib.fn2_capture_begin(_hip.stream_ptr()))
+            try:
+                self.launch()
+            finally:
+                g = C.c_void_p()
+                rc = self.lib.fn2_capture_end(_hip.stream_ptr(), C.byref(g))
+            _hip.check(rc)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = g
+
+    def __call__(self, input_a, input_b):
+        self.set_inputs(input_a, input_b)
+        self.launch()
+        return self.outputs
+
+    @property
+    def flops_per_forward(self):
+        return sum(f for _, f in self.layer_flops)
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.fn2_graph_destroy(self.graph)
+        except Exception:
+            pass

@@ -1,0 +1,86 @@
+"""Weights: seeded synthetic initialisation, (de)serialisation under the
+reference's variable names, and packing into the layout fn2_conv2d reads.
+
+No trained checkpoints exist offline, so parity and timing
+use seeded variance-scaling weights; real weights converted by the reference's
+scripts/caffe/convert_caffe_weights_to_npy.py (HWIO / HW-O-I, names
+``<scope>/<layer>/weights|biases``) load through ``load_npz`` unchanged.
+"""
+import numpy as np
+import torch
+
+from . import netdefs
+
+
+def init_weights(model, seed=1234, flow_gain=0.25, bias_std=0.02):
+    """Variance-scaling normal weights (the reference trains from
+    slim.variance_scaling_initializer(), flownet_s.py:31): std = sqrt(2/fan_in) for
+    LeakyReLU layers so activations stay O(1) through ~25 layers; linear layers
+    sqrt(1/fan_in); flow heads scaled by ``flow_gain`` so that 20*predict_flow2
+    spans several pixels (flow_warp then sees in- and out-of-range targets).
+    Small random biases exercise the bias path (the reference initialises them to 0)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for scope, layers in netdefs.model_scopes(model):
+        for (name, kind, k, stride, pad, cin, cout, act) in layers:
+            if kind == "conv":
+                fan_in = k * k * cin
+                std = np.sqrt((2.0 if act else 1.0) / fan_in)
+                if name.startswith("predict_flow"):
+                    std *= flow_gain
+                w[f"{scope}/{name}/weights"] = (rng.standard_normal((k, k, cin, cout)) * std).astype(np.float32)
+                w[f"{scope}/{name}/biases"] = (rng.standard_normal((cout,)) * bias_std).astype(np.float32)
+            else:
+                fan_in = 4 * cin  # each output pixel of a k4 s2 transposed conv sees 2x2 taps
+                std = np.sqrt((2.0 if act else 1.0) / fan_in)
+                w[f"{scope}/{name}/weights"] = (rng.standard_normal((k, k, cout, cin)) * std).astype(np.float32)
+    return w
+
+
+def save_npz(path, weights):
+    np.savez(path, **{k.replace("/", "__"): v for k, v in weights.items()})
+
+
+def load_npz(path):
+    with np.load(path) as z:
+        return {k.replace("__", "/"): z[k] for k in z.files}
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pack_conv(w_hwio, cout_tile, kstep_elems):
+    """[kh,kw,Cin,Cout] -> [cout_pad][kpad] fp32 with k = (tap, channel padded to 8)."""
+    kh, kw, cin, cout = w_hwio.shape
+    cin_pad = _round_up(cin, 8)
+    cout_pad = _round_up(cout, cout_tile)
+    kpad = _round_up(kh * kw * cin_pad, kstep_elems)
+    p = np.zeros((cout_pad, kh * kw, cin_pad), np.float32)
+    p[:cout, :, :cin] = np.transpose(w_hwio, (3, 0, 1, 2)).reshape(cout, kh * kw, cin)
+    out = np.zeros((cout_pad, kpad), np.float32)
+    out[:, :kh * kw * cin_pad] = p.reshape(cout_pad, -1)
+    return out, cin_pad, cout_pad, kpad
+
+
+def pack_deconv(w_hwoi, cout_tile, kstep_elems):
+    """[4,4,Cout,Cin] (HW-O-I) -> [4 phases][cout_pad][kpad]: phase (a,b) is the 2x2 stride-1
+    convolution with taps (ty,tx) <- (ky,kx) = (3-a-2ty, 3-b-2tx) producing output pixels (2y+a, 2x+b)."""
+    kh, kw, cout, cin = w_hwoi.shape
+    assert kh == 4 and kw == 4
+    cin_pad = _round_up(cin, 8)
+    cout_pad = _round_up(cout, cout_tile)
+    kpad = _round_up(4 * cin_pad, kstep_elems)
+    out = np.zeros((4, cout_pad, kpad), np.float32)
+    for a in range(2):
+        for b in range(2):
+            p = np.zeros((cout_pad, 4, cin_pad), np.float32)
+            for ty in range(2):
+                for tx in range(2):
+                    p[:cout, ty * 2 + tx, :cin] = w_hwoi[3 - a - 2 * ty, 3 - b - 2 * tx]
+            out[a * 2 + b, :, :4 * cin_pad] = p.reshape(cout_pad, -1)
+    return out, cin_pad, cout_pad, kpad
+
+
+def to_device(arr, dtype, device):
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(device=device, dtype=dtype).contiguous()

@@ -1,0 +1,177 @@
+/* flownet2_hip.h -- C ABI of libflownet2_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the FlowNet2 hot path of fperezgamonal/flownet2-tf
+ * (SURVEY.md section 8b).  The reference exposes its native code through the
+ * TensorFlow plugin ABI (tf.load_op_library + OpKernel::Compute); the plain
+ * functions under that ABI are what each entry point below replaces:
+ *
+ *   fn2_correlation_f32        <- Correlation(...)      src/ops/correlation/correlation_kernel.h:11-29
+ *                                 + Pad(...)            src/ops/correlation/pad.h:9-17
+ *                                 (op: src/correlation.py:7-14)
+ *   fn2_correlation_grad_f32   <- CorrelationGradA/B    src/ops/correlation/correlation_kernel.h:32-74
+ *                                 (op: src/correlation.py:17-35)
+ *   fn2_flow_warp_f32          <- FlowWarp(...)         src/ops/flow_warp/flow_warp.h:15-18
+ *                                 (op: src/flow_warp.py:7-8)
+ *   fn2_flow_warp_grad_f32     <- FlowWarpGrad(...)     src/ops/flow_warp/flow_warp.h:20-25
+ *                                 (op: src/flow_warp.py:11-15)
+ *   fn2_downsample_f32         <- Downsample(...)       src/ops/downsample/downsample_kernel.h:12-14
+ *                                 (op: src/downsample.py:7-8)
+ *   fn2_resize_bilinear_f32,
+ *   fn2_conv2d, fn2_deconv4x4s2_flow, fn2_* elementwise
+ *                              <- the TensorFlow builtins the model files call
+ *                                 (slim.conv2d / conv2d_transpose / resize_bilinear /
+ *                                 concat / LeakyReLU: src/flownet_s/flownet_s.py:26-111,
+ *                                 src/utils.py:401-421), which the reference gets from
+ *                                 TensorFlow + cuDNN (not vendored).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (the reference lets
+ *     TensorFlow own all memory: correlation_kernel.cc:61-80).  The library
+ *     allocates nothing and keeps no mutable global state except the
+ *     thread-local last-error string.
+ *   - Tensors are NHWC.  Op-surface entry points (suffix _f32) take dense
+ *     float32 tensors exactly like the reference ops.  Engine entry points take
+ *     an fn2_tensor view: dtype + channel stride + first channel, so that a
+ *     layer can read/write a channel slice of a concat buffer without copies.
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued
+ *     on it, nothing synchronises.
+ *   - Return value: FN2_OK (0) or a negative fn2_status; fn2_last_error() gives
+ *     the message.  Argument conditions mirror the reference's OP_REQUIRES
+ *     checks (correlation_kernel.cc:23,31-32,50-53; flow_warp.cc:22-30;
+ *     downsample_kernel.cc:19,25-26).
+ */
+#ifndef FLOWNET2_HIP_H_
+#define FLOWNET2_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  FN2_OK = 0,
+  FN2_ERR_INVALID_ARGUMENT = -1, /* shape / attribute check failed (errors::InvalidArgument) */
+  FN2_ERR_UNSUPPORTED = -2,      /* valid but not implemented for this dtype/shape */
+  FN2_ERR_HIP = -3               /* a HIP runtime call or kernel launch failed */
+} fn2_status;
+
+typedef enum { FN2_F32 = 0, FN2_BF16 = 1 } fn2_dtype;
+
+typedef enum { FN2_ACT_NONE = 0, FN2_ACT_LEAKY = 1 /* 0.55x + 0.45|x|, utils.py:401-405 */ } fn2_act;
+
+/* NHWC view of (a channel slice of) a device buffer. */
+typedef struct {
+  void* data;     /* element (n=0,y=0,x=0,channel 0 of the BUFFER) */
+  int32_t dtype;  /* fn2_dtype */
+  int32_t n, h, w;
+  int32_t c;      /* logical channels of the view */
+  int32_t cs;     /* channel stride of the buffer in elements (>= c0 + c) */
+  int32_t c0;     /* first channel of the view inside the buffer */
+} fn2_tensor;
+
+const char* fn2_last_error(void);
+int fn2_version(void);
+/* Fills name (<= cap bytes) with the gcnArchName of the current device, *cus with its CU count. */
+int fn2_device_info(char* name, int cap, int* cus);
+
+/* ---------------------------------------------------------------- op surface (float32, dense NHWC) */
+
+/* Output geometry of the correlation op (shape fn correlation_op.cc:9-51). */
+int fn2_correlation_out_shape(int h, int w, int kernel_size, int max_displacement, int stride_1,
+                              int stride_2, int pad, int* out_h, int* out_w, int* out_c);
+
+/* out[n,y,x,d] = 1/(k*k*C) * sum_{j,i,c} A0[n,y1+j,x1+i,c] * B0[n,y1+s2p+j,x1+s2o+i,c]
+ * (correlation_kernel.cu.cc:45-110); the zero padding is fused (no padded copy). */
+int fn2_correlation_f32(const float* a, const float* b, float* out, int n, int h, int w, int c,
+                        int kernel_size, int max_displacement, int stride_1, int stride_2, int pad,
+                        void* stream);
+
+/* grad_a, grad_b (same shape as a) from grad_out (correlation_grad_kernel.cu.cc:20-189). */
+int fn2_correlation_grad_f32(const float* grad_out, const float* a, const float* b, float* grad_a,
+                             float* grad_b, int n, int h, int w, int c, int kernel_size,
+                             int max_displacement, int stride_1, int stride_2, int pad, void* stream);
+
+/* out[n,y,x,:] = bilinear(image[n], x+u, y+v) inside the image else 0 (flow_warp.cu.cc:44-95). */
+int fn2_flow_warp_f32(const float* image, const float* flow, float* out, int n, int h, int w, int c,
+                      void* stream);
+
+/* image_grad (zeroed then scatter-added) and flow_grad (flow_warp_grad.cu.cc:30-86). */
+int fn2_flow_warp_grad_f32(const float* image, const float* flow, const float* grad_out,
+                           float* image_grad, float* flow_grad, int n, int h, int w, int c,
+                           void* stream);
+
+/* NaN-aware triangle-weighted area downsample (downsample_kernel_gpu.cu.cc:35-76). */
+int fn2_downsample_f32(const float* in, float* out, int n, int in_h, int in_w, int c, int out_h,
+                       int out_w, void* stream);
+
+/* tf.image.resize_bilinear(align_corners=True) of (scale * in). */
+int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in_w, int c, int out_h,
+                            int out_w, float scale, void* stream);
+
+/* ---------------------------------------------------------------- engine layer kernels */
+
+/* One convolution layer as an implicit GEMM on MFMA (fp32: v_mfma_f32_16x16x4_f32,
+ * bf16: v_mfma_f32_16x16x32_bf16), zero padding / bias / LeakyReLU / concat-slice write fused.
+ *   kind 0: slim.conv2d(pad(x,p), Cout, k, stride, 'VALID')        (flownet_s.py:39-50)
+ *   kind 1: antipad(slim.conv2d_transpose(x, Cout, 4, 2, 'VALID')) (flownet_s.py:53-63), computed as
+ *           four 2x2 stride-1 phase convolutions; no bias in the reference.
+ * `wgt` is the layer's weight pre-packed by fn2_pack_* layout rules (see DESIGN.md "weights"):
+ *   [phase][cout_pad][kpad] elements of in.dtype, k = (tap, channel) with channels padded to a
+ *   multiple of 8, kpad a multiple of 32 (bf16) / 16 (f32) elements; cout_pad a multiple of the
+ *   block's cout tile (fn2_conv2d_cout_tile). */
+typedef struct {
+  fn2_tensor in;       /* in.c = logical Cin; in.cs and in.c0 multiples of 8 */
+  fn2_tensor out;      /* out.c = Cout; out.dtype may be FN2_F32 while in is bf16 (flow heads) */
+  const void* wgt;
+  const float* bias;   /* [Cout] fp32 or NULL */
+  int32_t kind;        /* 0 conv, 1 deconv 4x4 s2 crop 1 */
+  int32_t kh, kw, stride, pad;
+  int32_t act;         /* fn2_act */
+  int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */
+  int32_t cout_pad;    /* rows per phase in the packed weight */
+  int32_t kpad;        /* elements per packed row */
+} fn2_conv_desc;
+
+/* Cout tile the kernel will use for this Cout (16, 32, 64 or 128): cout_pad must be a multiple. */
+int fn2_conv2d_cout_tile(int cout);
+int fn2_conv2d(const fn2_conv_desc* d, void* stream);
+
+/* upsample_flowXtoY: 2->2 channel conv-transpose 4x4 s2 crop 1, linear, no bias (flownet_s.py:60-63).
+ * in: fp32 [n,h,w,2] dense; w: fp32 [4][4][2 out][2 in] (reference HW-O-I layout); out: view with c=2. */
+int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, int n, int h, int wd,
+                      void* stream);
+
+/* images fp32 [n,h,w,3] x2 -> out view with 6 (pad 8) channels [a | b | 0 0]  (flownet_s.py:24) */
+int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, void* stream);
+/* image fp32 [n_img,h,w,3] -> batch rows [n0, n0+n_img) of the out view, 3 (pad 8) channels
+ * (the siamese towers of FlowNetC run as one 2N batch, flownet_c.py:30-37) */
+int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, void* stream);
+
+/* FlowNetC correlation inside the engine: a, b views over conv3 features (C multiple of 32),
+ * out = LeakyReLU(correlation(a, b, 1, md, 1, s2, md)) written into a channel slice
+ * (flownet_c.py:40-46). */
+int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_tensor* out,
+                          int max_displacement, int stride_2, int act, void* stream);
+
+/* Stacked-net input (flownet_cs.py:21-36): out view (16-channel padded) =
+ * [a(3) | b(3) | warp(b, flow)(3) | flow*0.05(2) | sqrt(sum_c (a-warp)^2)(1) | 0...]. */
+int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out,
+                    void* stream);
+
+/* FlowNet2 fusion input (flownet2.py:25-47): out view (16-channel padded) =
+ * [a(3) | flow_sd(2) | flow_css(2) | |sd| | |css| | |a-warp(b,sd)| | |a-warp(b,css)| | 0...]. */
+int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const float* flow_css,
+                     const fn2_tensor* out, void* stream);
+
+/* ---------------------------------------------------------------- launch-graph helpers (hipGraph) */
+int fn2_capture_begin(void* stream);
+int fn2_capture_end(void* stream, void** graph_exec);
+int fn2_graph_launch(void* graph_exec, void* stream);
+int fn2_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWNET2_HIP_H_ */
