@@ -1,0 +1,105 @@
+"""End-to-end parity: the HIP engine against the fp64 oracle of the reference graphs on the
+same seeded weights and inputs.  Tolerance from BASELINE.json north_star: mean EPE < 1e-3 px
+(fp32 MFMA path).  The bf16 path is reported against its own, looser, stated bound."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as refm
+
+pytestmark = pytest.mark.gpu
+
+EPE_TOL = 1e-3  # px, BASELINE.json north_star
+
+
+def images(n, h, w, seed):
+    """SURVEY.md section 8d synthetic pairs: uint8 noise image, second = first rolled by (3,-5) + noise."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (n, h, w, 3)).astype(np.float32)
+    # smooth a little so that the correlation has structure
+    a = (a + np.roll(a, 1, 1) + np.roll(a, 1, 2) + np.roll(a, (1, 1), (1, 2))) / 4
+    b = np.clip(np.roll(a, (3, -5), (1, 2)) + rng.uniform(-4, 4, a.shape), 0, 255)
+    return (a / 255).astype(np.float32), (b / 255).astype(np.float32)
+
+
+def epe(x, y):
+    d = np.asarray(x, np.float64) - np.asarray(y, np.float64)
+    return float(np.sqrt((d * d).sum(-1)).mean())
+
+
+def run(model, dtype, n, h, w, seed=0):
+    from src import weights as W
+    from src.engine import Engine
+    wts = W.init_weights(model, 1234)
+    a, b = images(n, h, w, seed)
+    eng = Engine(model, wts, n, h, w, dtype)
+    out = {k: v.float().cpu().numpy() for k, v in eng(a, b).items()}
+    want = refm.MODELS[model](wts, {"input_a": a, "input_b": b})
+    return out, want
+
+
+@pytest.mark.parametrize("model", ["FlowNetS", "FlowNetC", "FlowNetSD"])
+def test_single_nets_f32(model):
+    out, want = run(model, "f32", 2, 64, 128)
+    for k in ("predict_flow6", "predict_flow5", "predict_flow4", "predict_flow3", "predict_flow2"):
+        np.testing.assert_allclose(out[k], want[k], rtol=1e-3, atol=2e-4, err_msg=k)
+    e = epe(out["flow"], want["flow"])
+    mag = float(np.sqrt((want["flow"] ** 2).sum(-1)).mean())
+    print(model, "mean EPE vs oracle %.3e px (mean |flow| %.2f px)" % (e, mag))
+    assert e < EPE_TOL
+
+
+@pytest.mark.parametrize("model", ["FlowNetCS", "FlowNetCSS", "FlowNet2"])
+def test_stacked_nets_f32(model):
+    out, want = run(model, "f32", 1, 64, 64)
+    e = epe(out["flow"], want["flow"])
+    mag = float(np.sqrt((want["flow"] ** 2).sum(-1)).mean())
+    print(model, "mean EPE vs oracle %.3e px (mean |flow| %.2f px)" % (e, mag))
+    assert e < EPE_TOL
+
+
+def test_flownet_s_sample_pair_f32(golden_dir):
+    """BASELINE config 1: FlowNetS on data/samples/0img0.ppm + 0img1.ppm (512x384)."""
+    from src import weights as W
+    from src.net import imread
+    from src.flownet_s.flownet_s import FlowNetS
+    a = imread(os.path.join(golden_dir, "samples", "0img0.ppm"))
+    b = imread(os.path.join(golden_dir, "samples", "0img1.ppm"))
+    net = FlowNetS()
+    a1, b1, info = net.adapt_x(a, b)
+    assert info is None and a1.shape == (1, 384, 512, 3)
+    net.load_weights(None, seed=1234)
+    preds = net.model({"input_a": a1, "input_b": b1})
+    want = refm.flownet_s(net.weights, {"input_a": a1, "input_b": b1})
+    e = epe(preds["flow"].cpu().numpy(), want["flow"])
+    print("FlowNetS 512x384 sample pair: mean EPE vs oracle %.3e px" % e)
+    assert e < EPE_TOL
+
+
+@pytest.mark.parametrize("model", ["FlowNetS", "FlowNetC"])
+def test_bf16_path_bounded(model):
+    """bf16 activations/weights: not the parity path.  Stated bound: mean EPE < 5% of the mean
+    flow magnitude (bf16 has 8 mantissa bits; ~25 layers)."""
+    out, want = run(model, "bf16", 2, 64, 128)
+    e = epe(out["flow"], want["flow"])
+    mag = float(np.sqrt((want["flow"] ** 2).sum(-1)).mean())
+    print(model, "bf16 mean EPE vs oracle %.3e px (mean |flow| %.2f px)" % (e, mag))
+    assert e < 0.05 * mag
+
+
+def test_graph_replay_equals_eager():
+    from src import weights as W
+    from src.engine import Engine
+    wts = W.init_weights("FlowNetC", 1234)
+    a, b = images(1, 64, 64, 3)
+    eng = Engine("FlowNetC", wts, 1, 64, 64, "f32")
+    eager = eng(a, b)["flow"].clone()
+    eng.capture()
+    a2, b2 = images(1, 64, 64, 4)
+    eng(a2, b2)
+    torch.cuda.synchronize()
+    replay = eng(a, b)["flow"].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(eager, replay)
