@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: FlowNet forward on synthetic 512x384 pairs (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W [--model FlowNetC --batch 8 --dtype f32|bf16]
+
+A step = one forward pass of one batch of image pairs already resident in HBM.  N > 1 is
+launched by torch.distributed.run, one rank per GPU; pairs are independent, so ranks shard the
+batch with no data-path collective (weak scaling: `batch` pairs per GPU).  Rank 0 prints ONE
+JSON line (contract in the task statement; extra keys documented in DESIGN.md).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "flownet2-tf_amd"))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+K80_MS = {"FlowNetS": 38.067, "FlowNetC": 78.789, "FlowNetCS": 123.300, "FlowNetCSS": 161.186,
+          "FlowNetSD": 62.061, "FlowNet2": 276.641}  # reference README.md:71 (other hardware)
+
+
+def synth_pairs(n, h, w, seed0):
+    """uint8 noise image; second image = first rolled by (3,-5) px + noise +-4."""
+    a_l, b_l = [], []
+    for i in range(n):
+        rng = np.random.default_rng(seed0 + i)
+        a = rng.integers(0, 256, (h, w, 3)).astype(np.float32)
+        b = np.clip(np.roll(a, (3, -5), (0, 1)) + rng.uniform(-4, 4, a.shape), 0, 255)
+        a_l.append(a / 255.0)
+        b_l.append(b.astype(np.float32) / 255.0)
+    return np.stack(a_l).astype(np.float32), np.stack(b_l).astype(np.float32)
+
+
+def kernel_family(op_name, fn_name):
+    leaf = op_name.split("/")[-1]
+    if fn_name == "fn2_conv2d":
+        return "conv_igemm"
+    if fn_name == "fn2_correlation_fused":
+        return "corr_mfma"
+    return fn_name.replace("fn2_", "")
+
+
+def per_kernel_times(eng, steps):
+    """Eager pass with an event pair around every launch on the launch stream."""
+    n_ops = len(eng.ops)
+    acc = np.zeros(n_ops)
+    s = None
+    from src import _hip
+    for _ in range(steps):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ops + 1)]
+        s = _hip.stream_ptr()
+        evs[0].record()
+        for i, (name, fn, args) in enumerate(eng.ops):
+            rc = fn(*args, s)
+            if rc:
+                _hip.check(rc)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        for i in range(n_ops):
+            acc[i] += evs[i].elapsed_time(evs[i + 1])
+    return acc / steps  # ms per launch
+
+
+def cpu_baseline(model, h, w, seed):
+    """The NumPy oracle (CPU restatement of the reference graph) timed on the host cores:
+    one pair, one run (bounded sample of the same workload)."""
+    from oracle import models as refm
+    from src import weights as W
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    wts = W.init_weights(model, 1234)
+    a, b = synth_pairs(1, h, w, seed)
+    t0 = time.perf_counter()
+    refm.MODELS[model](wts, {"input_a": a, "input_b": b})
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": int(threads), "kind": "port",
+            "sample": "1 pair %s forward %dx%d, NumPy fp64 oracle, 1 run (%.1f s)" % (model, w, h, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="FlowNetC")
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print per-launch ms and TFLOP/s to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from src import weights as W
+    from src.engine import Engine
+    wts = W.init_weights(args.model, 1234)
+    eng = Engine(args.model, wts, args.batch, args.height, args.width, args.dtype)
+    a, b = synth_pairs(args.batch, args.height, args.width, seed0=1000 * rank)
+    eng.set_inputs(a, b)  # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        eng.capture()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.launch()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.launch()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / args.steps * 1e3
+    pairs_s = world * args.batch * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel event timing on the launch stream (eager, same K steps)
+        graph, eng.graph = eng.graph, None
+        per_op = per_kernel_times(eng, args.steps)
+        eng.graph = graph
+        fams = {}
+        flops = dict(eng.layer_flops)
+        for (name, fn, _), ms in zip(eng.ops, per_op):
+            f = kernel_family(name, fn.__name__)
+            d = fams.setdefault(f, {"ms": 0.0, "launches": 0, "flop": 0.0})
+            d["ms"] += ms
+            d["launches"] += 1
+            d["flop"] += flops.get(name, 0.0)
+        if args.per_layer:
+            for (name, fn, _), ms in zip(eng.ops, per_op):
+                fl = flops.get(name, 0.0)
+                sys.stderr.write("%-48s %9.4f ms %8.1f TFLOP/s\n" % (name, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+        dom = max(fams, key=lambda k: fams[k]["ms"])
+        D = fams[dom]
+        avg_ms = D["ms"] / D["launches"]
+        achieved = (D["flop"] / D["launches"]) / (avg_ms * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2),
+                    "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "launches_per_step": D["launches"], "avg_launch_ms": round(avg_ms, 5),
+                    "flop_per_launch": D["flop"] / D["launches"]}
+        kernels = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"]} for k, v in fams.items()}
+        out = {
+            "metric": "forward pairs/sec at 512x384 (%s)" % args.model, "value": round(pairs_s, 2),
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "ms_per_pair": round(ms_step / args.batch, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic", "config": {"workload": "%s forward, batch=%d synthetic %dx%d pairs per GPU, "
+                                            "seeded synthetic weights" % (args.model, args.batch, args.width,
+                                                                          args.height),
+                                            "pairs_per_gpu": args.batch, "parallelism": "dp%d (no collective)" % world},
+            "roofline": roofline, "kernels": kernels,
+            "model_gflop_per_pair": round(eng.flops_per_forward / args.batch / 1e9, 3),
+            "model_tflops": round(eng.flops_per_forward * args.steps / dt / 1e12, 2),
+            "reference_k80_ms_per_pair": K80_MS.get(args.model),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.model, args.height, args.width, seed=0)
+        else:
+            out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
