@@ -41,6 +41,10 @@ struct ConvArgs {
   int act;
   int deconv;
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
+  int splitk;  // K splits (blockIdx.z = phase*splitk + split); > 1 -> raw fp32 partials go to `ws`
+  int kper;    // k-steps per split
+  float* ws;   // [splitk][N*out_H*out_W][ws_cs] fp32 partial sums
+  int ws_cs;   // Cout rounded up to 4
 };
 
 template <typename OutT>
@@ -75,11 +79,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 
   int pad_y = p.pad, pad_x = p.pad, oy_off = 0, ox_off = 0, osc = 1;
   const T* wgt = reinterpret_cast<const T*>(p.wgt);
+  const int phase = blockIdx.z / p.splitk, split = blockIdx.z - phase * p.splitk;
   if (p.deconv) {
-    const int a = blockIdx.z >> 1, b = blockIdx.z & 1;
+    const int a = phase >> 1, b = phase & 1;
     pad_y = 1 - a; pad_x = 1 - b; oy_off = a; ox_off = b; osc = 2;
-    wgt += (size_t)blockIdx.z * p.cout_pad * p.ksteps * 4 * CH;
+    wgt += (size_t)phase * p.cout_pad * p.ksteps * 4 * CH;
   }
+  const int kt0 = split * p.kper;
+  const int kt1 = min(p.ksteps, kt0 + p.kper);
   const int m0 = blockIdx.x * BP;
   const int c0 = blockIdx.y * BC;
   const T* in = reinterpret_cast<const T*>(p.in);
@@ -102,8 +109,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   }
   const size_t wrow_elems = (size_t)p.ksteps * 4 * CH;
   // tap state of chunk column `cid`
-  int cc = cid % p.cin_chunks;
-  int tap = cid / p.cin_chunks;
+  const int q0 = kt0 * 4 + cid;
+  int cc = q0 % p.cin_chunks;
+  int tap = q0 / p.cin_chunks;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
 
   uint4 rp[NPR], rw[NWR];
@@ -169,13 +177,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) acc[t][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_step(0);
+  load_step(kt0);
   store_step(0);
   __syncthreads();
 
-  for (int kt = 0; kt < p.ksteps; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < p.ksteps;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
     if (more) {
       advance();
       load_step(kt + 1);
@@ -209,6 +217,26 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   // ---- epilogue: lane holds, per pixel tile, TC*4 consecutive couts of one pixel
   OutT* out = reinterpret_cast<OutT*>(p.out);
   const int cout_base = c0 + wc * TC * 16 + (lane >> 4) * (TC * 4);
+  if (p.splitk > 1) {
+    float* slab = p.ws + (size_t)split * p.N * p.out_H * p.out_W * p.ws_cs;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const int m = m0 + wp * 64 + pt * 16 + fi;
+      if (m >= p.M) continue;
+      const int n = m / (p.OH * p.OW);
+      const int rem = m - n * (p.OH * p.OW);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      float* po = slab + (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.ws_cs;
+#pragma unroll
+      for (int t = 0; t < TC; ++t) {
+        const int co = cout_base + t * 4;
+        if (co < p.ws_cs)
+          *reinterpret_cast<float4*>(po + co) =
+              make_float4(acc[t][pt][0], acc[t][pt][1], acc[t][pt][2], acc[t][pt][3]);
+      }
+    }
+    return;
+  }
   float bias[TC][4];
 #pragma unroll
   for (int t = 0; t < TC; ++t)
@@ -247,9 +275,107 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   }
 }
 
+// Split-K finalize: out = act(bias + sum_s slab[s]), one thread per (output pixel, 4 couts).
+template <typename OutT>
+__global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                              OutT* __restrict__ out, long npix, int ws_cs, int splitk,
+                                                              int Cout, int out_cs, int out_c0, int act, int vec_ok) {
+  const int groups = ws_cs / 4;
+  const long total = npix * groups;
+  const size_t slab = (size_t)npix * ws_cs;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / groups;
+    const int co = (int)(i - pix * groups) * 4;
+    float4 v = *reinterpret_cast<const float4*>(ws + pix * ws_cs + co);
+    for (int s = 1; s < splitk; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(ws + s * slab + pix * ws_cs + co);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (bias != nullptr && co + j < Cout) r[j] += bias[co + j];
+      if (act == FN2_ACT_LEAKY) r[j] = leaky(r[j]);
+    }
+    OutT* po = out + (size_t)pix * out_cs + out_c0 + co;
+    if (vec_ok && co + 3 < Cout) {
+      store4<OutT>(po, r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (co + j < Cout) po[j] = from_f32<OutT>(r[j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Flow heads (predict_flowN: 3x3, stride 1, pad 1, Cout = 2, linear; flownet_s.py:54-56).
+// Two output channels cannot feed a matrix core: HBM/L2-bound dot products.  One wavefront per
+// output pixel; the 64 lanes stride the (tap, 16-byte channel chunk) space, wave64 shuffle
+// reduction at the end.  Reads rows 0 and 1 of the same packed weight as the MFMA path.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void dot_chunk(const uint4& x, const uint4& w0, const uint4& w1, float& a0, float& a1);
+template <>
+__device__ __forceinline__ void dot_chunk<float>(const uint4& x, const uint4& w0, const uint4& w1, float& a0,
+                                                 float& a1) {
+  const float4 xv = __builtin_bit_cast(float4, x), u = __builtin_bit_cast(float4, w0), v = __builtin_bit_cast(float4, w1);
+  a0 += xv.x * u.x + xv.y * u.y + xv.z * u.z + xv.w * u.w;
+  a1 += xv.x * v.x + xv.y * v.y + xv.z * v.z + xv.w * v.w;
+}
+template <>
+__device__ __forceinline__ void dot_chunk<bf16_t>(const uint4& x, const uint4& w0, const uint4& w1, float& a0,
+                                                  float& a1) {
+  const unsigned xs[4] = {x.x, x.y, x.z, x.w}, us[4] = {w0.x, w0.y, w0.z, w0.w}, vs[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xl = __uint_as_float(xs[j] << 16), xh = __uint_as_float(xs[j] & 0xffff0000u);
+    a0 += xl * __uint_as_float(us[j] << 16) + xh * __uint_as_float(us[j] & 0xffff0000u);
+    a1 += xl * __uint_as_float(vs[j] << 16) + xh * __uint_as_float(vs[j] & 0xffff0000u);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) flow_head_kernel(const ConvArgs p) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const T* in = reinterpret_cast<const T*>(p.in);
+  const T* w0 = reinterpret_cast<const T*>(p.wgt);
+  const T* w1 = w0 + (size_t)p.ksteps * 4 * CH;
+  float* out = reinterpret_cast<float*>(p.out);
+  const int items = 9 * p.cin_chunks;
+  for (long m = wave; m < p.M; m += nwaves) {
+    const int x = (int)(m % p.W), y = (int)((m / p.W) % p.H);
+    const size_t nb = (size_t)(m / p.W / p.H) * p.H * p.W;
+    float a0 = 0.f, a1 = 0.f;
+    for (int q = lane; q < items; q += 64) {
+      const int tap = q / p.cin_chunks, cc = q - tap * p.cin_chunks;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int iy = y + ky - 1, ix = x + kx - 1;
+      if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+      const uint4 xv = *reinterpret_cast<const uint4*>(in + (nb + (size_t)iy * p.W + ix) * p.in_cs + p.in_c0 + cc * CH);
+      const size_t wo = (size_t)q * CH;  // k index = tap*cin_pad + cc*CH
+      dot_chunk<T>(xv, *reinterpret_cast<const uint4*>(w0 + wo), *reinterpret_cast<const uint4*>(w1 + wo), a0, a1);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64);
+      a1 += __shfl_xor(a1, off, 64);
+    }
+    if (lane == 0) {
+      float* po = out + (size_t)m * p.out_cs + p.out_c0;
+      po[0] = a0 + (p.bias ? p.bias[0] : 0.f);
+      po[1] = a1 + (p.bias ? p.bias[1] : 0.f);
+    }
+  }
+}
+
 template <typename T, typename OutT>
-static int launch_conv(const ConvArgs& a, int tile, int phases, hipStream_t s) {
+static int launch_conv(const ConvArgs& a, int tile, int phases_, hipStream_t s) {
   dim3 block(256);
+  const int phases = phases_ * a.splitk;
   if (tile == 128) {
     dim3 grid(cdiv(a.M, 128), a.cout_pad / 128, phases);
     hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 4, 2, 2>), grid, block, 0, s, a);
@@ -341,7 +467,17 @@ extern "C" {
 
 int fn2_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16; }
 
-int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
+}  // extern "C"
+
+namespace fn2 {
+
+static bool is_flow_head(const fn2_conv_desc* d) {
+  return d->kind == 0 && d->out.c == 2 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+         d->out.dtype == FN2_F32 && d->act == FN2_ACT_NONE;
+}
+
+// validate + fill everything except the split-K fields
+static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int* phases_out) {
   FN2_REQUIRE(d, "conv2d: null descriptor");
   int rc = check_view(&d->in, "conv2d input");
   if (rc) return rc;
@@ -355,13 +491,13 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   FN2_REQUIRE(d->in.c0 + d->cin_pad <= d->in.cs, "conv2d: padded input channels exceed the buffer stride");
   const int esz = d->in.dtype == FN2_BF16 ? 2 : 4;
   const int CH = 16 / esz;
-  FN2_REQUIRE(d->kpad % (4 * CH) == 0, "conv2d: kpad must be a multiple of one k-step");
+  FN2_REQUIRE(d->kpad > 0 && d->kpad % (4 * CH) == 0, "conv2d: kpad must be a multiple of one k-step");
   const int tile = fn2_conv2d_cout_tile(d->out.c);
   FN2_REQUIRE(d->cout_pad % tile == 0 && d->cout_pad >= d->out.c, "conv2d: cout_pad must be a multiple of the cout tile");
   FN2_REQUIRE(d->act == FN2_ACT_NONE || d->act == FN2_ACT_LEAKY, "conv2d: bad activation");
   FN2_REQUIRE(d->out.dtype == d->in.dtype || d->out.dtype == FN2_F32, "conv2d: output dtype must be the input dtype or fp32");
 
-  ConvArgs a;
+  ConvArgs& a = *out;
   a.in = d->in.data; a.wgt = d->wgt; a.bias = d->bias; a.out = d->out.data;
   a.N = d->in.n; a.H = d->in.h; a.W = d->in.w; a.in_cs = d->in.cs; a.in_c0 = d->in.c0;
   a.cin_chunks = d->cin_pad / CH;
@@ -393,10 +529,83 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   a.cout_pad = d->cout_pad;
   a.act = d->act;
   a.vec_ok = (d->out.cs % 4 == 0) && (d->out.c0 % 4 == 0);
+  a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = (a.Cout + 3) / 4 * 4;
+  *tile_out = tile;
+  *phases_out = phases;
+  return FN2_OK;
+}
+
+// Preferred split-K factor: fill >= ~2 blocks per CU on layers whose output grid is small
+// (the 6x8 .. 24x32 resolution layers: weight-bandwidth bound, SURVEY.md section 7 "hard parts").
+static int preferred_split(const ConvArgs& a, int tile, int phases) {
+  const int bp = tile == 128 ? 128 : 256;
+  const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
+  if (blocks >= 384) return 1;
+  int s = (int)((512 + blocks - 1) / blocks);
+  const int maxs = a.ksteps / 8;
+  if (s > maxs) s = maxs;
+  if (s > 16) s = 16;
+  if (s < 2) return 1;
+  const int kper = cdiv(a.ksteps, s);
+  return cdiv(a.ksteps, kper);  // no empty splits
+}
+
+static int64_t split_bytes(const ConvArgs& a, int s) {
+  return (int64_t)s * a.N * a.out_H * a.out_W * a.ws_cs * (int64_t)sizeof(float);
+}
+
+}  // namespace fn2
+
+extern "C" {
+
+int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d) {
+  ConvArgs a;
+  int tile, phases;
+  if (build_args(d, &a, &tile, &phases) != FN2_OK) return 0;
+  if (is_flow_head(d)) return 0;
+  const int s = preferred_split(a, tile, phases);
+  return s > 1 ? split_bytes(a, s) : 0;
+}
+
+int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
+  ConvArgs a;
+  int tile, phases;
+  int rc = build_args(d, &a, &tile, &phases);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (d->in.dtype == FN2_F32) return launch_conv<float, float>(a, tile, phases, s);
-  if (d->out.dtype == FN2_BF16) return launch_conv<bf16_t, bf16_t>(a, tile, phases, s);
-  return launch_conv<bf16_t, float>(a, tile, phases, s);
+  if (is_flow_head(d)) {
+    const int blocks = grid_for((long)a.M * 64, 256);
+    if (d->in.dtype == FN2_F32)
+      hipLaunchKernelGGL(flow_head_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(flow_head_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+    FN2_CHECK_LAUNCH("flow_head");
+    return FN2_OK;
+  }
+  int sk = preferred_split(a, tile, phases);
+  while (sk > 1 && (d->workspace == nullptr || split_bytes(a, sk) > d->workspace_bytes)) --sk;
+  if (sk > 1) {
+    a.kper = cdiv(a.ksteps, sk);
+    sk = cdiv(a.ksteps, a.kper);
+  }
+  if (sk > 1) {
+    a.splitk = sk;
+    a.ws = reinterpret_cast<float*>(d->workspace);
+  }
+  if (d->in.dtype == FN2_F32) rc = launch_conv<float, float>(a, tile, phases, s);
+  else if (d->out.dtype == FN2_BF16) rc = launch_conv<bf16_t, bf16_t>(a, tile, phases, s);
+  else rc = launch_conv<bf16_t, float>(a, tile, phases, s);
+  if (rc || a.splitk == 1) return rc;
+  const long npix = (long)a.N * a.out_H * a.out_W;
+  const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
+  if (d->out.dtype == FN2_F32)
+    hipLaunchKernelGGL(splitk_finalize_kernel<float>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (float*)a.out, npix,
+                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
+  else
+    hipLaunchKernelGGL(splitk_finalize_kernel<bf16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (bf16_t*)a.out,
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
+  FN2_CHECK_LAUNCH("splitk_finalize");
+  return FN2_OK;
 }
 
 int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, int n, int h, int wd,

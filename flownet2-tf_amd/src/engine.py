@@ -51,7 +51,9 @@ class Engine:
         self.in_a = torch.zeros((self.N, self.H, self.W, 3), dtype=torch.float32, device=self.device)
         self.in_b = torch.zeros_like(self.in_a)
         self.graph = None
+        self.conv_descs = []
         self.outputs = self._build()
+        self._alloc_workspace()
 
     # ------------------------------------------------------------------ buffers / views
     def _buf(self, name, n, h, w, c, dtype=None):
@@ -95,6 +97,7 @@ class Engine:
         d.act = _hip.ACT_LEAKY if act else _hip.ACT_NONE
         d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
         self.keep += [d, wdev, bias]
+        self.conv_descs.append(d)
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d))
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         taps = k * k if kind == "conv" else 4
@@ -114,6 +117,16 @@ class Engine:
         self._op(name, self.lib.fn2_resize_bilinear_f32, _hip.ptr(src_f32), _hip.ptr(dst), n, h, w, c, self.H,
                  self.W, C.c_float(scale))
         return dst
+
+    def _alloc_workspace(self):
+        """One fp32 split-K scratch buffer shared by every layer (launches are ordered on one stream)."""
+        need = max([int(self.lib.fn2_conv2d_workspace_bytes(C.byref(d))) for d in self.conv_descs] + [0])
+        self.workspace = None
+        if need > 0:
+            self.workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+            for d in self.conv_descs:
+                d.workspace = self.workspace.data_ptr()
+                d.workspace_bytes = need
 
     # ------------------------------------------------------------------ sub-networks
     def _refine(self, scope, tag, L, c6_1, cats, interconv):

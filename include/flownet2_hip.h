@@ -17,7 +17,7 @@
  *   fn2_downsample_f32         <- Downsample(...)       src/ops/downsample/downsample_kernel.h:12-14
  *                                 (op: src/downsample.py:7-8)
  *   fn2_resize_bilinear_f32,
- *   fn2_conv2d, fn2_deconv4x4s2_flow, fn2_* elementwise
+ *   fn2_conv2d, fn2_upsample_flow, fn2_* fused elementwise
  *                              <- the TensorFlow builtins the model files call
  *                                 (slim.conv2d / conv2d_transpose / resize_bilinear /
  *                                 concat / LeakyReLU: src/flownet_s/flownet_s.py:26-111,
@@ -132,10 +132,16 @@ typedef struct {
   int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */
   int32_t cout_pad;    /* rows per phase in the packed weight */
   int32_t kpad;        /* elements per packed row */
+  void* workspace;     /* fp32 scratch for split-K partial sums, or NULL (then no split-K) */
+  int64_t workspace_bytes;
 } fn2_conv_desc;
 
 /* Cout tile the kernel will use for this Cout (16, 32, 64 or 128): cout_pad must be a multiple. */
 int fn2_conv2d_cout_tile(int cout);
+/* Bytes of workspace with which this layer would use its preferred split-K factor (0 = none needed).
+ * The caller owns the workspace (the reference: ctx->allocate_temp, correlation_kernel.cc:66-80);
+ * one buffer of the maximum over layers can be shared by all launches on a stream. */
+int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d);
 int fn2_conv2d(const fn2_conv_desc* d, void* stream);
 
 /* upsample_flowXtoY: 2->2 channel conv-transpose 4x4 s2 crop 1, linear, no bias (flownet_s.py:60-63).

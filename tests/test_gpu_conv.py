@@ -15,7 +15,8 @@ def rnd(shape, seed, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
 
 
-def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0, cout_off=0, extra_out=0):
+def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0, cout_off=0, extra_out=0,
+             use_ws=True):
     """Drive the C ABI directly.  x: [N,H,W,Cin] fp32.  Returns fp32 numpy [N,oh,ow,Cout]."""
     from src import _hip, weights as W
     lib = _hip.lib()
@@ -50,6 +51,12 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
     d.stride, d.pad = stride, pad
     d.act = 1 if act else 0
     d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
+    need = int(lib.fn2_conv2d_workspace_bytes(C.byref(d)))
+    ws = None
+    if use_ws and need > 0:
+        ws = torch.full(((need + 3) // 4,), float("nan"), dtype=torch.float32, device="cuda")  # poisoned
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    run_conv.last_ws_bytes = need if use_ws else 0
     _hip.check(lib.fn2_conv2d(C.byref(d), _hip.stream_ptr()))
     torch.cuda.synchronize()
     res = out.float().cpu().numpy()
@@ -115,6 +122,28 @@ def test_conv_bf16_matches_oracle_on_bf16_rounded_inputs(k, s, p, cin, cout, H, 
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
     got16 = run_conv(x, w, b, "conv", k, s, p, True, "bf16")
     np.testing.assert_allclose(got16, want, rtol=1e-2, atol=1e-2)  # + one bf16 output rounding
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_splitk_equals_single_pass(dtype):
+    """Small output grid + long K (conv6_1-like): the split-K path (workspace given) and the
+    single-pass path (no workspace) agree with the oracle and with each other."""
+    x = torch.from_numpy(rnd((2, 6, 8, 256), 9)).bfloat16().float().numpy()
+    w = torch.from_numpy(rnd((3, 3, 256, 192), 10, (2.0 / (9 * 256)) ** 0.5)).bfloat16().float().numpy()
+    b = rnd((192,), 11, 0.1)
+    want = refnn.conv2d(x, w, b, stride=1, padding=1, activation=refnn.leaky_relu)
+    got_split = run_conv(x, w, b, "conv", 3, 1, 1, True, dtype, out_f32=True, cout_off=8)
+    assert run_conv.last_ws_bytes > 0  # this shape must take the split-K path
+    got_single = run_conv(x, w, b, "conv", 3, 1, 1, True, dtype, out_f32=True, cout_off=8, use_ws=False)
+    np.testing.assert_allclose(got_split, want, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got_single, want, rtol=2e-5, atol=2e-5)
+    # deconv phases with split-K
+    xd = rnd((1, 3, 4, 512), 12)
+    wd = rnd((4, 4, 256, 512), 13, (2.0 / (4 * 512)) ** 0.5)
+    wantd = refnn.conv2d_transpose(xd, wd, activation=refnn.leaky_relu)
+    gotd = run_conv(xd, wd, None, "deconv", 4, 2, 1, True, "f32")
+    assert run_conv.last_ws_bytes > 0
+    np.testing.assert_allclose(gotd, wantd, rtol=2e-5, atol=2e-5)
 
 
 def test_upsample_flow_matches_oracle():
