@@ -18,47 +18,9 @@
 //
 // Replaces, for the reference, slim.conv2d / slim.conv2d_transpose (cuDNN) at
 // src/flownet_s/flownet_s.py:39-104 and the same call sites in flownet_c/sd/2.
-#include "fn2_common.h"
+#include "conv_common.h"
 
 namespace fn2 {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-struct ConvArgs {
-  const void* in;
-  const void* wgt;
-  const float* bias;
-  void* out;
-  int N, H, W, in_cs, in_c0;
-  int cin_chunks;  // chunks per tap
-  int KH, KW, stride, pad;
-  int OH, OW;  // pixel grid of the GEMM (per phase for deconv)
-  int M;       // N*OH*OW
-  int out_H, out_W, out_cs, out_c0, Cout;
-  int ksteps;  // packed row length / 4 chunks
-  int cout_pad;
-  int act;
-  int deconv;
-  int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
-  int splitk;  // K splits (blockIdx.z = phase*splitk + split); > 1 -> raw fp32 partials go to `ws`
-  int kper;    // k-steps per split
-  float* ws;   // [splitk][N*out_H*out_W][ws_cs] fp32 partial sums
-  int ws_cs;   // Cout rounded up to 4
-};
-
-template <typename OutT>
-__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
-template <>
-__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-}
-template <>
-__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-  bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
-  *reinterpret_cast<bf16x4*>(p) = v;
-}
 
 // TC: 16-cout MFMA tiles per wave; WC x WP waves over (cout, pixels); each wave owns 64 pixels.
 template <typename T, typename OutT, int TC, int WC, int WP>
@@ -530,6 +492,10 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   a.act = d->act;
   a.vec_ok = (d->out.cs % 4 == 0) && (d->out.c0 % 4 == 0);
   a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = (a.Cout + 3) / 4 * 4;
+  FN2_REQUIRE(d->wgt_layout == 0 || d->wgt_layout == 1, "conv2d: bad wgt_layout");
+  if (d->wgt_layout == 1)
+    FN2_REQUIRE(conv_fast_ok(d->in.dtype, d->cin_pad, d->out.c) && !is_flow_head(d),
+                "conv2d: wgt_layout 1 given but this layer does not run on the LDS-DMA kernel");
   *tile_out = tile;
   *phases_out = phases;
   return FN2_OK;
@@ -557,6 +523,10 @@ static int64_t split_bytes(const ConvArgs& a, int s) {
 }  // namespace fn2
 
 extern "C" {
+
+int fn2_conv2d_weight_layout(int in_dtype, int cin_pad, int cout) {
+  return (cout != 2 && conv_fast_ok(in_dtype, cin_pad, cout)) ? 1 : 0;
+}
 
 int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d) {
   ConvArgs a;
@@ -592,7 +562,14 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     a.splitk = sk;
     a.ws = reinterpret_cast<float*>(d->workspace);
   }
-  if (d->in.dtype == FN2_F32) rc = launch_conv<float, float>(a, tile, phases, s);
+  if (d->wgt_layout == 1) {
+    // LDS-DMA kernel: a stage is two generic k-steps (the tap never changes inside a stage)
+    a.ksteps = a.ksteps / 2;
+    a.kper = cdiv(a.kper, 2);
+    a.splitk = cdiv(a.ksteps, a.kper);
+    if (a.splitk == 1) a.ws = nullptr;
+    rc = launch_conv_fast(a, d->in.dtype, d->out.dtype, tile, phases, s);
+  } else if (d->in.dtype == FN2_F32) rc = launch_conv<float, float>(a, tile, phases, s);
   else if (d->out.dtype == FN2_BF16) rc = launch_conv<bf16_t, bf16_t>(a, tile, phases, s);
   else rc = launch_conv<bf16_t, float>(a, tile, phases, s);
   if (rc || a.splitk == 1) return rc;

@@ -1,0 +1,51 @@
+// Shared between conv.hip (generic implicit-GEMM kernel) and conv2.hip (LDS-DMA fast path).
+#pragma once
+#include "fn2_common.h"
+
+namespace fn2 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ConvArgs {
+  const void* in;
+  const void* wgt;
+  const float* bias;
+  void* out;
+  int N, H, W, in_cs, in_c0;
+  int cin_chunks;  // chunks per tap
+  int KH, KW, stride, pad;
+  int OH, OW;  // pixel grid of the GEMM (per phase for deconv)
+  int M;       // N*OH*OW
+  int out_H, out_W, out_cs, out_c0, Cout;
+  int ksteps;  // packed row length / 4 chunks
+  int cout_pad;
+  int act;
+  int deconv;
+  int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
+  int splitk;  // K splits (blockIdx.z = phase*splitk + split); > 1 -> raw fp32 partials go to `ws`
+  int kper;    // k-steps per split
+  float* ws;   // [splitk][N*out_H*out_W][ws_cs] fp32 partial sums
+  int ws_cs;   // Cout rounded up to 4
+};
+
+template <typename OutT>
+__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+
+// conv2.hip: the fast path.  Returns FN2_ERR_UNSUPPORTED when (dtype, tile) has no instantiation.
+int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s);
+// true when the fast kernel covers this geometry (then the packed weight must use the permuted-64 row order)
+bool conv_fast_ok(int in_dtype, int cin_pad, int cout);
+
+}  // namespace fn2

@@ -27,7 +27,7 @@ class Fn2ConvDesc(C.Structure):
     _fields_ = [("inp", Fn2Tensor), ("out", Fn2Tensor), ("wgt", C.c_void_p), ("bias", C.c_void_p),
                 ("kind", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("act", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
-                ("kpad", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 _i, _p, _f = C.c_int, C.c_void_p, C.c_float
@@ -47,6 +47,7 @@ PROTOTYPES = {
     "fn2_downsample_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "fn2_resize_bilinear_f32": (_i, [_p, _p] + [_i] * 6 + [_f, _p]),
     "fn2_conv2d_cout_tile": (_i, [_i]),
+    "fn2_conv2d_weight_layout": (_i, [_i, _i, _i]),
     "fn2_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(Fn2ConvDesc)]),
     "fn2_conv2d": (_i, [C.POINTER(Fn2ConvDesc), _p]),
     "fn2_upsample_flow": (_i, [_p, _p, _tp, _i, _i, _i, _p]),

@@ -57,7 +57,9 @@ class Engine:
 
     # ------------------------------------------------------------------ buffers / views
     def _buf(self, name, n, h, w, c, dtype=None):
-        cs = _round_up(c, 8) if dtype is None else c
+        # channel stride: multiples of 64 keep every consumer on the LDS-DMA conv kernel
+        # (a tap's channel run is then whole 128-byte lines); small stems stay at multiples of 8
+        cs = (_round_up(c, 64) if c > 32 else _round_up(c, 8)) if dtype is None else c
         t = torch.zeros((n, h, w, cs), dtype=self.tdtype if dtype is None else dtype, device=self.device)
         assert name not in self.bufs, name
         self.bufs[name] = t
@@ -79,11 +81,17 @@ class Engine:
         assert sc == cin and dc == cout, (scope, name, sc, cin, dc, cout)
         tile = self.lib.fn2_conv2d_cout_tile(cout)
         wname = f"{scope}/{name}/weights"
+        dt_code = _hip.FN2_BF16 if self.dtype_name == "bf16" else _hip.FN2_F32
+        cin_pad = _round_up(cin, 8)
+        cin64 = _round_up(cin, 64)
+        if cin > 32 and sc0 + cin64 <= sbuf.shape[3] and self.lib.fn2_conv2d_weight_layout(dt_code, cin64, cout) == 1:
+            cin_pad = cin64
+        layout = self.lib.fn2_conv2d_weight_layout(dt_code, cin_pad, cout)
         if kind == "conv":
-            packed, cin_pad, cout_pad, kpad = W.pack_conv(self.weights[wname], tile, self.kstep)
+            packed, cin_pad, cout_pad, kpad = W.pack_conv(self.weights[wname], tile, self.kstep, cin_pad, layout)
             bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
         else:
-            packed, cin_pad, cout_pad, kpad = W.pack_deconv(self.weights[wname], tile, self.kstep)
+            packed, cin_pad, cout_pad, kpad = W.pack_deconv(self.weights[wname], tile, self.kstep, cin_pad, layout)
             bias = None
         wdev = W.to_device(packed, self.tdtype, self.device)
         d = _hip.Fn2ConvDesc()
@@ -96,6 +104,7 @@ class Engine:
         d.stride, d.pad = stride, pad
         d.act = _hip.ACT_LEAKY if act else _hip.ACT_NONE
         d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
+        d.wgt_layout = layout
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d))

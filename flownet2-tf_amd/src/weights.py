@@ -50,25 +50,44 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def pack_conv(w_hwio, cout_tile, kstep_elems):
-    """[kh,kw,Cin,Cout] -> [cout_pad][kpad] fp32 with k = (tap, channel padded to 8)."""
+def _permute_rows64(rows):
+    """Row order of the LDS-DMA kernel (fn2_conv2d_weight_layout == 1): inside every group of 64
+    rows, packed row t*16 + g*4 + r holds output channel g*16 + t*4 + r (t, g, r in 0..3)."""
+    n = rows.shape[0]
+    assert n % 64 == 0
+    idx = np.arange(64).reshape(4, 4, 4)            # [t][g][r] -> packed row index
+    src = np.empty(64, np.int64)
+    for t in range(4):
+        for g in range(4):
+            for r in range(4):
+                src[idx[t, g, r]] = g * 16 + t * 4 + r
+    full = (np.arange(n // 64)[:, None] * 64 + src[None, :]).reshape(-1)
+    return rows[full]
+
+
+def pack_conv(w_hwio, cout_tile, kstep_elems, cin_pad=None, layout=0):
+    """[kh,kw,Cin,Cout] -> [cout_pad][kpad] fp32 with k = (tap, channel padded to cin_pad)."""
     kh, kw, cin, cout = w_hwio.shape
-    cin_pad = _round_up(cin, 8)
+    cin_pad = _round_up(cin, 8) if cin_pad is None else cin_pad
+    assert cin_pad >= cin and cin_pad % 8 == 0
     cout_pad = _round_up(cout, cout_tile)
     kpad = _round_up(kh * kw * cin_pad, kstep_elems)
     p = np.zeros((cout_pad, kh * kw, cin_pad), np.float32)
     p[:cout, :, :cin] = np.transpose(w_hwio, (3, 0, 1, 2)).reshape(cout, kh * kw, cin)
     out = np.zeros((cout_pad, kpad), np.float32)
     out[:, :kh * kw * cin_pad] = p.reshape(cout_pad, -1)
+    if layout == 1:
+        out = _permute_rows64(out)
     return out, cin_pad, cout_pad, kpad
 
 
-def pack_deconv(w_hwoi, cout_tile, kstep_elems):
+def pack_deconv(w_hwoi, cout_tile, kstep_elems, cin_pad=None, layout=0):
     """[4,4,Cout,Cin] (HW-O-I) -> [4 phases][cout_pad][kpad]: phase (a,b) is the 2x2 stride-1
     convolution with taps (ty,tx) <- (ky,kx) = (3-a-2ty, 3-b-2tx) producing output pixels (2y+a, 2x+b)."""
     kh, kw, cout, cin = w_hwoi.shape
     assert kh == 4 and kw == 4
-    cin_pad = _round_up(cin, 8)
+    cin_pad = _round_up(cin, 8) if cin_pad is None else cin_pad
+    assert cin_pad >= cin and cin_pad % 8 == 0
     cout_pad = _round_up(cout, cout_tile)
     kpad = _round_up(4 * cin_pad, kstep_elems)
     out = np.zeros((4, cout_pad, kpad), np.float32)
@@ -78,7 +97,9 @@ def pack_deconv(w_hwoi, cout_tile, kstep_elems):
             for ty in range(2):
                 for tx in range(2):
                     p[:cout, ty * 2 + tx, :cin] = w_hwoi[3 - a - 2 * ty, 3 - b - 2 * tx]
-            out[a * 2 + b, :, :4 * cin_pad] = p.reshape(cout_pad, -1)
+            ph = np.zeros((cout_pad, kpad), np.float32)
+            ph[:, :4 * cin_pad] = p.reshape(cout_pad, -1)
+            out[a * 2 + b] = _permute_rows64(ph) if layout == 1 else ph
     return out, cin_pad, cout_pad, kpad
 
 

@@ -132,12 +132,18 @@ typedef struct {
   int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */
   int32_t cout_pad;    /* rows per phase in the packed weight */
   int32_t kpad;        /* elements per packed row */
+  int32_t wgt_layout;  /* row order of the packed weight: value of fn2_conv2d_weight_layout() */
   void* workspace;     /* fp32 scratch for split-K partial sums, or NULL (then no split-K) */
   int64_t workspace_bytes;
 } fn2_conv_desc;
 
 /* Cout tile the kernel will use for this Cout (16, 32, 64 or 128): cout_pad must be a multiple. */
 int fn2_conv2d_cout_tile(int cout);
+/* Row order the kernel chosen for (dtype, cin_pad, cout) expects in the packed weight:
+ *   0: row r = output channel r;
+ *   1: LDS-DMA fast path: inside every group of 64 rows, row t*16+g*4+r = output channel g*16+t*4+r
+ *      (t,g,r in 0..3), so that a lane's 16 accumulators are 16 consecutive channels. */
+int fn2_conv2d_weight_layout(int in_dtype, int cin_pad, int cout);
 /* Bytes of workspace with which this layer would use its preferred split-K factor (0 = none needed).
  * The caller owns the workspace (the reference: ctx->allocate_temp, correlation_kernel.cc:66-80);
  * one buffer of the maximum over layers can be shared by all launches on a stream. */

@@ -16,14 +16,14 @@ def rnd(shape, seed, scale=1.0):
 
 
 def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0, cout_off=0, extra_out=0,
-             use_ws=True):
+             use_ws=True, force_generic=False):
     """Drive the C ABI directly.  x: [N,H,W,Cin] fp32.  Returns fp32 numpy [N,oh,ow,Cout]."""
     from src import _hip, weights as W
     lib = _hip.lib()
     td = torch.float32 if dtype == "f32" else torch.bfloat16
     N, H, Wd, cin = x.shape
     cout = w.shape[3] if kind == "conv" else w.shape[2]
-    cs_in = (cin_off + cin + 7) // 8 * 8
+    cs_in = (cin_off + cin + 63) // 64 * 64 if cin > 32 else (cin_off + cin + 7) // 8 * 8
     xin = torch.zeros((N, H, Wd, cs_in), dtype=td, device="cuda")
     xin[..., cin_off:cin_off + cin] = torch.from_numpy(x).cuda().to(td)
     if kind == "conv":
@@ -35,10 +35,17 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
     out = torch.full((N, oh, ow, cs_out), 7.0, dtype=od, device="cuda")
     tile = lib.fn2_conv2d_cout_tile(cout)
     kstep = 32 if dtype == "bf16" else 16
+    code = 1 if dtype == "bf16" else 0
+    cin_pad = (cin + 7) // 8 * 8
+    cin64 = (cin + 63) // 64 * 64
+    if not force_generic and cin > 32 and lib.fn2_conv2d_weight_layout(code, cin64, cout) == 1:
+        cin_pad = cin64
+    layout = 0 if force_generic else lib.fn2_conv2d_weight_layout(code, cin_pad, cout)
+    run_conv.last_layout = layout
     if kind == "conv":
-        packed, cin_pad, cout_pad, kpad = W.pack_conv(w, tile, kstep)
+        packed, cin_pad, cout_pad, kpad = W.pack_conv(w, tile, kstep, cin_pad, layout)
     else:
-        packed, cin_pad, cout_pad, kpad = W.pack_deconv(w, tile, kstep)
+        packed, cin_pad, cout_pad, kpad = W.pack_deconv(w, tile, kstep, cin_pad, layout)
     wdev = torch.from_numpy(packed).cuda().to(td).contiguous()
     bdev = torch.from_numpy(b).cuda() if b is not None else None
     d = _hip.Fn2ConvDesc()
@@ -51,6 +58,7 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
     d.stride, d.pad = stride, pad
     d.act = 1 if act else 0
     d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
+    d.wgt_layout = layout
     need = int(lib.fn2_conv2d_workspace_bytes(C.byref(d)))
     ws = None
     if use_ws and need > 0:
@@ -91,6 +99,21 @@ def test_conv_f32_matches_oracle(k, s, p, cin, cout, H, W):
     want = refnn.conv2d(x, w, b, stride=s, padding=p, activation=refnn.leaky_relu)
     got = run_conv(x, w, b, "conv", k, s, p, True, "f32")
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)  # fp32 accumulation-order tolerance
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fast_and_generic_kernels_agree(dtype):
+    """The LDS-DMA kernel (permuted weight rows) and the generic kernel on the same layer."""
+    x = torch.from_numpy(rnd((2, 12, 16, 128), 20)).bfloat16().float().numpy()
+    w = torch.from_numpy(rnd((3, 3, 128, 192), 21, (2.0 / (9 * 128)) ** 0.5)).bfloat16().float().numpy()
+    b = rnd((192,), 22, 0.1)
+    want = refnn.conv2d(x, w, b, stride=2, padding=1, activation=refnn.leaky_relu)
+    fast = run_conv(x, w, b, "conv", 3, 2, 1, True, dtype, out_f32=True, cout_off=8, use_ws=False)
+    assert run_conv.last_layout == 1
+    gen = run_conv(x, w, b, "conv", 3, 2, 1, True, dtype, out_f32=True, cout_off=8, use_ws=False, force_generic=True)
+    assert run_conv.last_layout == 0
+    np.testing.assert_allclose(fast, want, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gen, want, rtol=2e-5, atol=2e-5)
 
 
 def test_conv_f32_linear_no_bias_and_slices():
