@@ -39,15 +39,6 @@ def synth_pairs(n, h, w, seed0):
     return np.stack(a_l).astype(np.float32), np.stack(b_l).astype(np.float32)
 
 
-def kernel_family(op_name, fn_name):
-    leaf = op_name.split("/")[-1]
-    if fn_name == "fn2_conv2d":
-        return "conv_igemm"
-    if fn_name == "fn2_correlation_fused":
-        return "corr_mfma"
-    return fn_name.replace("fn2_", "")
-
-
 def per_kernel_times(eng, steps):
     """Eager pass with an event pair around every launch on the launch stream."""
     n_ops = len(eng.ops)
@@ -155,8 +146,8 @@ def main():
         eng.graph = graph
         fams = {}
         flops = dict(eng.layer_flops)
-        for (name, fn, _), ms in zip(eng.ops, per_op):
-            f = kernel_family(name, fn.__name__)
+        for (name, fn, _), kern, ms in zip(eng.ops, eng.kernel_of, per_op):
+            f = kern
             d = fams.setdefault(f, {"ms": 0.0, "launches": 0, "flop": 0.0})
             d["ms"] += ms
             d["launches"] += 1

@@ -19,6 +19,7 @@
 // Replaces, for the reference, slim.conv2d / slim.conv2d_transpose (cuDNN) at
 // src/flownet_s/flownet_s.py:39-104 and the same call sites in flownet_c/sd/2.
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace fn2 {
 
@@ -155,22 +156,23 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     for (int t = 0; t < TC; ++t) fa[t] = lds[buf][a_off[t]];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) fb[pt] = lds[buf][b_off[pt]];
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int t = 0; t < TC; ++t) {
+      for (int t = 0; t < TC; ++t)
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
-        if constexpr (sizeof(T) == 2) {
+        for (int pt = 0; pt < 4; ++pt)
           acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]),
-                                                              __builtin_bit_cast(bf16x8, fb[pt]),
-                                                              acc[t][pt], 0, 0, 0);
-        } else {
-          const float4 va = __builtin_bit_cast(float4, fa[t]), vb = __builtin_bit_cast(float4, fb[pt]);
-          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc[t][pt], 0, 0, 0);
-          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc[t][pt], 0, 0, 0);
-          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, vb.z, acc[t][pt], 0, 0, 0);
-          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, vb.w, acc[t][pt], 0, 0, 0);
-        }
-      }
+                                                              __builtin_bit_cast(bf16x8, fb[pt]), acc[t][pt], 0, 0, 0);
+    } else {
+      // independent accumulators back to back (fp32 MFMA: 40-cycle dependent latency, 32-cycle issue)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < TC; ++t)
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt)
+            acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, fa[t])[j],
+                                                             __builtin_bit_cast(f32x4, fb[pt])[j], acc[t][pt], 0, 0, 0);
     }
     if (more) store_step(buf ^ 1);
     __syncthreads();
@@ -492,6 +494,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   a.act = d->act;
   a.vec_ok = (d->out.cs % 4 == 0) && (d->out.c0 % 4 == 0);
   a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = (a.Cout + 3) / 4 * 4;
+  { const char* e = getenv("FN2_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
   FN2_REQUIRE(d->wgt_layout == 0 || d->wgt_layout == 1, "conv2d: bad wgt_layout");
   if (d->wgt_layout == 1)
     FN2_REQUIRE(conv_fast_ok(d->in.dtype, d->cin_pad, d->out.c) && !is_flow_head(d),

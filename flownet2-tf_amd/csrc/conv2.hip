@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   int ky = tap / p.KW, kx = tap - ky * p.KW;
 
   auto issue_stage = [&](int buf) {
+    if (!(p.dbg & 2))
 #pragma unroll
     for (int j = 0; j < NWI; ++j) {
       __builtin_amdgcn_global_load_lds((gptr_t)wsrc[j], (lptr_t)&lds[buf][(wave * (BC / 4) + j * 8) * 8], 16, 0, 0);
@@ -112,6 +113,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     }
     const bool tap_ok = ky < p.KH;
     const int cbase = p.in_c0 + sc * 8 * CH;
+    if (!(p.dbg & 1))
 #pragma unroll
     for (int j = 0; j < NPI; ++j) {
       const int iy = iy0[j] + ky, ix = ix0[j] + kx;
@@ -141,6 +143,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   for (int s = kt0; s < kt1; ++s) {
     const int buf = (s - kt0) & 1;
     if (s + 1 < kt1) issue_stage(buf ^ 1);
+    if (!(p.dbg & 4))
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = (ks * 4 + fg) ^ fsw;
@@ -149,22 +152,25 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       for (int t = 0; t < 4; ++t) fa[t] = lds[buf][(wc * 64 + t * 16 + fi) * 8 + ch];
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) fb[pt] = lds[buf][(BC + wp * 64 + pt * 16 + fi) * 8 + ch];
+      if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-          if constexpr (sizeof(T) == 2) {
+          for (int pt = 0; pt < 4; ++pt)
             acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]),
                                                                 __builtin_bit_cast(bf16x8, fb[pt]),
                                                                 acc[t][pt], 0, 0, 0);
-          } else {
-            const float4 va = __builtin_bit_cast(float4, fa[t]), vb = __builtin_bit_cast(float4, fb[pt]);
-            acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc[t][pt], 0, 0, 0);
-            acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, vb.y, acc[t][pt], 0, 0, 0);
-            acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, vb.z, acc[t][pt], 0, 0, 0);
-            acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, vb.w, acc[t][pt], 0, 0, 0);
-          }
-        }
+      } else {
+        // fp32 16x16x4: 40-cycle dependent latency vs 32-cycle issue -> walk the 16 accumulators
+        // for each k component instead of chaining 4 MFMAs on one accumulator
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+              acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, fa[t])[j],
+                                                               __builtin_bit_cast(f32x4, fb[pt])[j], acc[t][pt], 0, 0, 0);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,0 +1,35 @@
+"""Multi-GPU inference: image pairs are independent, so a batch shards across ranks (one
+process per GPU) with NO collective on the data path; the only communication is the optional
+gather of finished flow fields on rank 0.  The reference is single-GPU (SURVEY.md section 2:
+no distributed code), so this module has no counterpart there.
+
+torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced split: the first n_items % world ranks get one extra item."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_flows(local_flows, n_total, dst=0):
+    """Collect per-rank flow shards [n_local, H, W, 2] on rank `dst` in global pair order.
+    Ragged shards are padded to the largest shard for the gather and trimmed afterwards."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_flows
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    n_max = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((n_max,) + tuple(local_flows.shape[1:]), dtype=local_flows.dtype, device=local_flows.device)
+    pad[:local_flows.shape[0]] = local_flows
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

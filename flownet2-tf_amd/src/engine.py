@@ -45,6 +45,7 @@ class Engine:
         self.kstep = 32 if dtype == "bf16" else 16
         self.weights = weights
         self.ops = []      # (name, fn, args) ; args exclude the trailing stream
+        self.kernel_of = []  # per op: the device kernel (template instantiation) that does the work
         self.keep = []     # keep ctypes structs / tensors alive
         self.bufs = {}
         self.layer_flops = []  # (name, flop) algorithmic, for roofline accounting
@@ -69,7 +70,8 @@ class Engine:
     def _v(buf, c=None, c0=0):
         return _hip.view(buf, c, c0)
 
-    def _op(self, name, fn, *args):
+    def _op(self, name, fn, *args, kernel=None):
+        self.kernel_of.append(kernel if kernel is not None else fn.__name__.replace("fn2_", ""))
         self.ops.append((name, fn, args))
 
     # ------------------------------------------------------------------ layers
@@ -107,7 +109,16 @@ class Engine:
         d.wgt_layout = layout
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
-        self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d))
+        tn = "__bf16" if self.dtype_name == "bf16" else "float"
+        if kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1:
+            kern = f"flow_head_kernel<{tn}>"
+        elif layout == 1:
+            kern = f"conv_igemm2_kernel<{tn}, {tn}, {'2, 2' if tile == 128 else '1, 4'}>"
+        else:
+            shape = {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4", 16: "1, 1, 4"}[tile]
+            on = "float" if dbuf.dtype == torch.float32 else tn
+            kern = f"conv_igemm_kernel<{tn}, {on}, {shape}>"
+        self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d), kernel=kern)
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         taps = k * k if kind == "conv" else 4
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * taps * cin * cout))
@@ -223,8 +234,9 @@ class Engine:
         net = self._buf(f"{tag}/corr_concat", N, H // 8, W_ // 8, 473)  # [conv_redir(32) | corr(441)], :46
         va, vb, vo = self._v(c3a, 256, 0), self._v(c3b, 256, 0), self._v(net, 441, 32)
         self.keep += [va, vb, vo]
+        tn = "__bf16" if self.dtype_name == "bf16" else "float"
         self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
-                 _hip.ACT_LEAKY)  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
+                 _hip.ACT_LEAKY, kernel=f"corr_mfma_kernel<{tn}, {tn}, {8 if self.dtype_name == 'bf16' else 16}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
         self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
         self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
         self._conv(scope, L["conv3_1"], (net, 0, 473), (cats[3], 0, 256))

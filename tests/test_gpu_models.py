@@ -78,6 +78,15 @@ def test_flownet_s_sample_pair_f32(golden_dir):
     assert e < EPE_TOL
 
 
+def test_flownet2_full_size_f32():
+    """BASELINE config 3 shape (one pair of it): FlowNet2 full stack at 512x384, fp32 MFMA path."""
+    out, want = run("FlowNet2", "f32", 1, 384, 512)
+    e = epe(out["flow"], want["flow"])
+    mag = float(np.sqrt((want["flow"] ** 2).sum(-1)).mean())
+    print("FlowNet2 512x384 mean EPE vs oracle %.3e px (mean |flow| %.2f px)" % (e, mag))
+    assert e < EPE_TOL
+
+
 @pytest.mark.parametrize("model", ["FlowNetS", "FlowNetC"])
 def test_bf16_path_bounded(model):
     """bf16 activations/weights: not the parity path.  Stated bound: mean EPE < 5% of the mean
