@@ -496,6 +496,14 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = (a.Cout + 3) / 4 * 4;
   { const char* e = getenv("FN2_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
   FN2_REQUIRE(d->wgt_layout == 0 || d->wgt_layout == 1, "conv2d: bad wgt_layout");
+  a.in_bytes = 0;
+  if (d->wgt_layout == 1) {
+    // the LDS-DMA kernel addresses both operands through buffer descriptors with 32-bit byte offsets
+    const long in_bytes = (long)d->in.n * d->in.h * d->in.w * d->in.cs * esz;
+    FN2_REQUIRE(in_bytes < (1L << 31), "conv2d: input buffer >= 2 GiB is not addressable by the LDS-DMA kernel");
+    FN2_REQUIRE((long)d->cout_pad * d->kpad * esz < (1L << 31), "conv2d: packed weight >= 2 GiB per phase");
+    a.in_bytes = (int)in_bytes;
+  }
   if (d->wgt_layout == 1)
     FN2_REQUIRE(conv_fast_ok(d->in.dtype, d->cin_pad, d->out.c) && !is_flow_head(d),
                 "conv2d: wgt_layout 1 given but this layer does not run on the LDS-DMA kernel");

@@ -1,29 +1,41 @@
 // Fast path of the implicit-GEMM convolution (gfx950): layers whose per-tap channel run is a
 // multiple of 128 bytes (Cin_pad % 64 == 0 in bf16, % 32 in fp32) and Cout > 32.
 //
-// Differences from the generic kernel in conv.hip:
-//   * a stage is 128 bytes of channels per operand row (two bf16 MFMA k-steps), so a stage never
-//     straddles a filter tap: the tap (ky, kx) is wave-uniform scalar state and every pixel row is
-//     fetched as one full 128-byte line (8 lanes x 16 B);
-//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging VGPRs and no
-//     ds_write: one wave instruction fills 8 LDS rows.  The LDS image is lane-linear, so the
-//     bank-conflict XOR swizzle is applied to the per-lane SOURCE address and again on the read
-//     (phys chunk = chunk ^ ((row >> 1) & 7): conflict-free ds_read_b128 fragment reads);
-//     out-of-image taps (the reference's explicit zero pad, utils.py:408-412) and rows past the end
-//     of the pixel grid read a 16-byte zero page instead of being predicated;
-//   * 2-stage software pipeline: the DMA of stage s+1 is in flight under the 32 (bf16) / 128
-//     (fp32) MFMAs of stage s; one s_waitcnt vmcnt(0) + barrier per stage;
-//   * weight rows are stored by the host in the permuted order that makes each lane's 16 accumulator
-//     registers 16 CONSECUTIVE output channels (packed row t*16+g*4+r <-> cout g*16+t*4+r inside every
-//     64-row group), so the epilogue writes 32-byte (bf16) / 64-byte (fp32) runs per pixel.
+//   D[cout][pixel] += W[cout][k] * X[pixel][k],  k = (tap, channel);  block tile 128 cout x 128 px
+//   (or 64 x 256), 4 waves, each a 64 x 64 tile = 2 x 2 MFMA tiles of 32 x 32
+//   (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32).
+//
+// What the in-process ablations (tools/ab_conv.py, FN2_CONV_DBG) showed about the first version:
+// the K loop was bound by vector-ALU ISSUE, not by the matrix pipe or by bytes -- ~100 address
+// VALU per stage for the operand fetches plus 8 of every 16 cycles of each 16x16x32 MFMA.  Hence:
+//   * operands go HBM/L2 -> LDS by LDS-DMA through BUFFER descriptors (buffer_load_dwordx4 ... lds):
+//     a lane's byte offset inside the tensor is computed once, the per-stage motion (tap, channel
+//     block) is a scalar offset, and out-of-image taps (the reference's explicit zero pad,
+//     utils.py:408-412) / rows past the end of the pixel grid are an out-of-range offset that the
+//     descriptor's range check turns into zeros: 4 VALU per pixel piece, 0 per weight piece;
+//   * 32x32 MFMA tiles: half the matrix instructions per FLOP of the 16x16 shape;
+//   * a stage is 128 bytes of channels per operand row, so it never straddles a filter tap (the tap
+//     is wave-uniform scalar state) and every row is fetched as one full 128-byte line;
+//   * the LDS image is lane-linear (8 rows x 128 B per wave instruction); the bank-conflict XOR
+//     swizzle (phys chunk = chunk ^ ((row >> 1) & 7)) is applied to the SOURCE offset and again on
+//     the ds_read_b128 fragment reads (conflict-free for the 32-row x 2-chunk operand pattern);
+//   * 2-stage pipeline: the next stage's DMA is issued in front of this stage's MFMAs (issuing the
+//     pieces between MFMA groups measured slower for both dtypes once the loop was clean), MFMA
+//     fragments double-buffered in registers, one s_waitcnt vmcnt(0) + barrier per stage;
+//   * weight rows are permuted by the host inside every group of 32 (packed row (r&3)+8(r>>2)+4h
+//     <-> cout 16h+r) so that the 16 accumulator registers of a lane are 16 CONSECUTIVE output
+//     channels: the epilogue stores 32-byte (bf16) / 64-byte (fp32) runs per pixel.
 #include "conv_common.h"
+
+#include <type_traits>
+#include <utility>
 
 namespace fn2 {
 
-__device__ uint4 g_zero_page[4];  // all-zero source for padded taps / tail rows
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr unsigned kOobOffset = 0x80000000u;  // >= num_records of every descriptor (tensors < 2 GiB)
 
 template <typename OutT>
 __device__ __forceinline__ void store16v(OutT* p, const float* v);
@@ -46,11 +58,13 @@ __device__ __forceinline__ void store16v<bf16_t>(bf16_t* p, const float* v) {
 
 template <typename T, typename OutT, int WC, int WP>
 __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
+  constexpr int ESZ = (int)sizeof(T);
   constexpr int BC = WC * 64, BP = WP * 64;
   static_assert(WC * WP == 4, "4 waves per block");
-  constexpr int NWI = BC / 32;  // weight-row DMA instructions per wave per stage (8 rows each)
-  constexpr int NPI = BP / 32;  // pixel-row DMA instructions per wave per stage
+  constexpr int NWI = BC / 32;  // weight-row DMA pieces per wave per stage (8 rows each)
+  constexpr int NPI = BP / 32;  // pixel-row DMA pieces per wave per stage
   constexpr int ROWS = BC + BP;
   __shared__ uint4 lds[2][ROWS * 8];
 
@@ -61,29 +75,33 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   int pad_y = p.pad, pad_x = p.pad, oy_off = 0, ox_off = 0, osc = 1;
   const T* wgt = reinterpret_cast<const T*>(p.wgt);
   const int phase = blockIdx.z / p.splitk, split = blockIdx.z - phase * p.splitk;
-  const size_t wrow_elems = (size_t)p.ksteps * 8 * CH;
+  const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
   if (p.deconv) {
     const int a = phase >> 1, b = phase & 1;
     pad_y = 1 - a; pad_x = 1 - b; oy_off = a; ox_off = b; osc = 2;
-    wgt += (size_t)phase * p.cout_pad * wrow_elems;
+    wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
   }
   const int kt0 = split * p.kper;
   const int kt1 = min(p.ksteps, kt0 + p.kper);
   const int m0 = blockIdx.x * BP;
   const int c0 = blockIdx.y * BC;
-  const T* in = reinterpret_cast<const T*>(p.in);
 
-  // ---- DMA source state.  Lane -> (row lane>>3 of the instruction's 8 rows, physical chunk lane&7)
+  // buffer descriptors: base, stride 0, num_records bytes, raw dword format
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, (int)(p.cout_pad * wrow_bytes), 0x00020000);
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+
+  // ---- per-lane DMA offsets.  Lane -> (row lane>>3 of the piece's 8 rows, physical chunk lane&7)
   const int lrow = lane >> 3, lphys = lane & 7;
-  const T* wsrc[NWI];
+  unsigned woff[NWI];
 #pragma unroll
   for (int j = 0; j < NWI; ++j) {
     const int row = wave * (BC / 4) + j * 8 + lrow;
-    const int c = lphys ^ ((row >> 1) & 7);
-    wsrc[j] = wgt + (size_t)(c0 + row) * wrow_elems + ((size_t)kt0 * 8 + c) * CH;
+    woff[j] = (unsigned)(c0 + row) * wrow_bytes + (unsigned)((lphys ^ ((row >> 1) & 7)) * 16);
   }
-  int iy0[NPI], ix0[NPI], pc[NPI];
-  size_t pbase[NPI];
+  // pixel rows: byte offset of (n, iy0, ix0, chunk) -- may be "negative" while the tap is out of the
+  // image -- and a validity mask: bit ky: 0 <= iy0+ky < H; bit 8+kx: 0 <= ix0+kx < W
+  int roff[NPI];
+  unsigned vmask[NPI];
 #pragma unroll
   for (int j = 0; j < NPI; ++j) {
     const int row = wave * (BP / 4) + j * 8 + lrow;
@@ -93,144 +111,171 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     const int n = mm / (p.OH * p.OW);
     const int rem = mm - n * (p.OH * p.OW);
     const int oy = rem / p.OW, ox = rem - oy * p.OW;
-    iy0[j] = v ? oy * p.stride - pad_y : -(1 << 20);  // tail rows: never in range -> zero page
-    ix0[j] = ox * p.stride - pad_x;
-    pbase[j] = (size_t)n * p.H * p.W;
-    pc[j] = lphys ^ ((row >> 1) & 7);
+    const int iy0 = oy * p.stride - pad_y, ix0 = ox * p.stride - pad_x;
+    roff[j] = (((n * p.H + iy0) * p.W + ix0) * p.in_cs + p.in_c0) * ESZ + (lphys ^ ((row >> 1) & 7)) * 16;
+    unsigned mk = 0;
+    if (v) {
+      for (int k = 0; k < p.KH; ++k) mk |= (unsigned)(iy0 + k >= 0 && iy0 + k < p.H) << k;
+      for (int k = 0; k < p.KW; ++k) mk |= (unsigned)(ix0 + k >= 0 && ix0 + k < p.W) << (8 + k);
+    }
+    vmask[j] = mk;
   }
-  // wave-uniform tap state of stage kt0
+  // wave-uniform state of stage kt0: tap (ky, kx) and 128-byte block `sc` inside the tap's channel run
   const int spt = p.cin_chunks >> 3;  // stages per tap
   int tap = kt0 / spt;
   int sc = kt0 - tap * spt;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
+  int wstage = kt0;  // absolute stage index of the next weight fetch
 
-  auto issue_stage = [&](int buf) {
-    if (!(p.dbg & 2))
-#pragma unroll
-    for (int j = 0; j < NWI; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)wsrc[j], (lptr_t)&lds[buf][(wave * (BC / 4) + j * 8) * 8], 16, 0, 0);
-      wsrc[j] += 8 * CH;
+  auto issue_piece = [&](auto piece_c, int buf) {
+    constexpr int i = decltype(piece_c)::value;
+    if constexpr (i < NWI) {
+      if (!(p.dbg & 2))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)&lds[buf][(wave * (BC / 4) + i * 8) * 8], 16, woff[i],
+                                                 wstage * 128, 0, 0);
+    } else {
+      constexpr int j = i - NWI;
+      const unsigned tbit = (1u << ky) | (1u << (8 + kx));
+      const int toff = ((ky * p.W + kx) * p.in_cs + sc * 8 * CH) * ESZ;
+      const unsigned voff = ((vmask[j] & tbit) == tbit) ? (unsigned)(roff[j] + toff) : kOobOffset;
+      if (!(p.dbg & 1))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)&lds[buf][(BC + wave * (BP / 4) + j * 8) * 8], 16, voff,
+                                                 0, 0, 0);
     }
-    const bool tap_ok = ky < p.KH;
-    const int cbase = p.in_c0 + sc * 8 * CH;
-    if (!(p.dbg & 1))
-#pragma unroll
-    for (int j = 0; j < NPI; ++j) {
-      const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-      const bool ok = tap_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const T* src = ok ? in + (pbase[j] + (size_t)iy * p.W + ix) * p.in_cs + cbase + pc[j] * CH
-                        : reinterpret_cast<const T*>(g_zero_page);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds[buf][(BC + wave * (BP / 4) + j * 8) * 8], 16, 0, 0);
-    }
+  };
+  auto advance = [&]() {
+    ++wstage;
     if (++sc == spt) {
       sc = 0;
       if (++kx == p.KW) { kx = 0; ++ky; }
     }
   };
+  auto issue_stage = [&](int buf) {
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      (issue_piece(std::integral_constant<int, I>{}, buf), ...);
+    }(std::make_integer_sequence<int, NWI + NPI>{});
+    advance();
+  };
 
-  // ---- fragment addresses: row (l&15) of a 16-row tile, chunk ks*4 + (l>>4), swizzled
-  const int fi = lane & 15, fg = lane >> 4, fsw = (fi >> 1) & 7;
-  f32x4 acc[4][4];
+  // ---- fragment addresses: row r = l&31 of a 32-row tile, chunk 2*ks + (l>>5), swizzled by the row
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) acc[t][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[tc][tp][q] = 0.f;
 
   issue_stage(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // NOTE: nothing conditional may wrap the MFMAs: an `if` around them made hipcc shuttle all 64
+  // accumulators between VGPRs and AGPRs four times per stage (256 v_accvgpr moves, the dominant VALU
+  // cost of the first version of this loop -- found with SQ_INSTS_VALU and the .s).
   for (int s = kt0; s < kt1; ++s) {
     const int buf = (s - kt0) & 1;
-    if (s + 1 < kt1) issue_stage(buf ^ 1);
-    if (!(p.dbg & 4))
+    if (s + 1 < kt1) issue_stage(buf ^ 1);  // next stage's DMA in flight under this stage's MFMAs
+    const uint4* A = &lds[buf][(wc * 64 + fr) * 8];
+    const uint4* B = &lds[buf][(BC + wp * 64 + fr) * 8];
+    // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
+    uint4 fa[2][2], fb[2][2];
+    {
+      const int ch = fh ^ fsw;
+      fa[0][0] = A[ch]; fa[0][1] = A[32 * 8 + ch];
+      fb[0][0] = B[ch]; fb[0][1] = B[32 * 8 + ch];
+    }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = (ks * 4 + fg) ^ fsw;
-      uint4 fa[4], fb[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fa[t] = lds[buf][(wc * 64 + t * 16 + fi) * 8 + ch];
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt) fb[pt] = lds[buf][(BC + wp * 64 + pt * 16 + fi) * 8 + ch];
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < 4) {
+        const int ch = ((ks + 1) * 2 + fh) ^ fsw;
+        fa[nxt][0] = A[ch]; fa[nxt][1] = A[32 * 8 + ch];
+        fb[nxt][0] = B[ch]; fb[nxt][1] = B[32 * 8 + ch];
+      }
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
-          for (int pt = 0; pt < 4; ++pt)
-            acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]),
-                                                                __builtin_bit_cast(bf16x8, fb[pt]),
-                                                                acc[t][pt], 0, 0, 0);
+          for (int tp = 0; tp < 2; ++tp)
+            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][tc]),
+                                                                  __builtin_bit_cast(bf16x8, fb[cur][tp]),
+                                                                  acc[tc][tp], 0, 0, 0);
       } else {
-        // fp32 16x16x4: 40-cycle dependent latency vs 32-cycle issue -> walk the 16 accumulators
-        // for each k component instead of chaining 4 MFMAs on one accumulator
+        // chunk = 4 floats; MFMA j takes element j of both operands (a permutation of k shared by both)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+          for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
-              acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, fa[t])[j],
-                                                               __builtin_bit_cast(f32x4, fb[pt])[j], acc[t][pt], 0, 0, 0);
+            for (int tp = 0; tp < 2; ++tp)
+              acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, fa[cur][tc])[j],
+                                                                 __builtin_bit_cast(f32x4, fb[cur][tp])[j],
+                                                                 acc[tc][tp], 0, 0, 0);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // ---- epilogue.  Packed row t*16 + g*4 + r holds cout g*16 + t*4 + r of this wave's 64-cout group,
-  // so acc[0..3][pt][0..3] of a lane are 16 consecutive output channels of one pixel.
+  // ---- epilogue.  Lane (pixel fr of tile tp, half fh) holds couts [16 fh, 16 fh + 16) of cout tile tc.
   OutT* out = reinterpret_cast<OutT*>(p.out);
-  const int cout_base = c0 + wc * 64 + fg * 16;
   if (p.splitk > 1) {
     float* slab = p.ws + (size_t)split * p.N * p.out_H * p.out_W * p.ws_cs;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      const int m = m0 + wp * 64 + pt * 16 + fi;
+    for (int tp = 0; tp < 2; ++tp) {
+      const int m = m0 + wp * 64 + tp * 32 + fr;
       if (m >= p.M) continue;
       const int n = m / (p.OH * p.OW);
       const int rem = m - n * (p.OH * p.OW);
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
       float* po = slab + (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.ws_cs;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int co = cout_base + t * 4;
-        if (co < p.ws_cs)
-          *reinterpret_cast<float4*>(po + co) =
-              make_float4(acc[t][pt][0], acc[t][pt][1], acc[t][pt][2], acc[t][pt][3]);
-      }
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = c0 + wc * 64 + tc * 32 + fh * 16 + q * 4;
+          if (co < p.ws_cs)
+            *reinterpret_cast<float4*>(po + co) = make_float4(acc[tc][tp][4 * q], acc[tc][tp][4 * q + 1],
+                                                              acc[tc][tp][4 * q + 2], acc[tc][tp][4 * q + 3]);
+        }
     }
     return;
   }
-  float bias[16];
+  const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) bias[q] = (p.bias != nullptr && cout_base + q < p.Cout) ? p.bias[cout_base + q] : 0.f;
-  const bool full16 = (cout_base + 15 < p.Cout) && (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
+  for (int tc = 0; tc < 2; ++tc) {
+    const int cout_base = c0 + wc * 64 + tc * 32 + fh * 16;
+    float bias[16];
 #pragma unroll
-  for (int pt = 0; pt < 4; ++pt) {
-    const int m = m0 + wp * 64 + pt * 16 + fi;
-    if (m >= p.M) continue;
-    const int n = m / (p.OH * p.OW);
-    const int rem = m - n * (p.OH * p.OW);
-    const int oy = rem / p.OW, ox = rem - oy * p.OW;
-    OutT* po = out + (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.out_cs +
-               p.out_c0 + cout_base;
-    float v[16];
+    for (int q = 0; q < 16; ++q) bias[q] = (p.bias != nullptr && cout_base + q < p.Cout) ? p.bias[cout_base + q] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int tp = 0; tp < 2; ++tp) {
+      const int m = m0 + wp * 64 + tp * 32 + fr;
+      if (m >= p.M) continue;
+      const int n = m / (p.OH * p.OW);
+      const int rem = m - n * (p.OH * p.OW);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      OutT* po = out + (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.out_cs +
+                 p.out_c0 + cout_base;
+      float v[16];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = acc[t][pt][r] + bias[t * 4 + r];
+      for (int q = 0; q < 16; ++q) {
+        float x = acc[tc][tp][q] + bias[q];
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
-        v[t * 4 + r] = x;
+        v[q] = x;
       }
-    if (full16) {
-      store16v<OutT>(po, v);
-    } else {
+      if (vec16 && cout_base + 15 < p.Cout) {
+        store16v<OutT>(po, v);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        if (cout_base + q < p.Cout) po[q] = from_f32<OutT>(v[q]);
+        for (int q = 0; q < 16; ++q)
+          if (cout_base + q < p.Cout) po[q] = from_f32<OutT>(v[q]);
+      }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 template <typename T, typename OutT>

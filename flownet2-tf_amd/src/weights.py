@@ -51,17 +51,17 @@ def _round_up(x, m):
 
 
 def _permute_rows64(rows):
-    """Row order of the LDS-DMA kernel (fn2_conv2d_weight_layout == 1): inside every group of 64
-    rows, packed row t*16 + g*4 + r holds output channel g*16 + t*4 + r (t, g, r in 0..3)."""
+    """Row order of the LDS-DMA kernel (fn2_conv2d_weight_layout == 1): inside every group of 32
+    rows, packed row (r & 3) + 8 * (r >> 2) + 4 * h holds output channel 16 * h + r (h in 0..1,
+    r in 0..15) -- the 32x32 MFMA accumulator layout read backwards, so that the 16 registers of a
+    lane are 16 consecutive output channels."""
     n = rows.shape[0]
-    assert n % 64 == 0
-    idx = np.arange(64).reshape(4, 4, 4)            # [t][g][r] -> packed row index
-    src = np.empty(64, np.int64)
-    for t in range(4):
-        for g in range(4):
-            for r in range(4):
-                src[idx[t, g, r]] = g * 16 + t * 4 + r
-    full = (np.arange(n // 64)[:, None] * 64 + src[None, :]).reshape(-1)
+    assert n % 32 == 0
+    src = np.empty(32, np.int64)
+    for h in range(2):
+        for r in range(16):
+            src[(r & 3) + 8 * (r >> 2) + 4 * h] = 16 * h + r
+    full = (np.arange(n // 32)[:, None] * 32 + src[None, :]).reshape(-1)
     return rows[full]
 
 

@@ -70,10 +70,10 @@ def test_pack_conv_layouts():
     assert np.all(p[70:] == 0) and np.all(p[:, 72:] == 0) and np.all(p.reshape(128, -1)[:, 5:8] == 0)
     q, _, _, _ = W.pack_conv(w, 128, 32, cin_pad=64, layout=1)
     assert q.shape == (128, 9 * 64)
-    # permuted-64: packed row t*16+g*4+r <- cout g*16+t*4+r
-    for (t, g, r) in [(0, 0, 0), (1, 2, 3), (3, 3, 1), (2, 0, 2)]:
-        assert np.array_equal(q[t * 16 + g * 4 + r, :5], w[0, 0, :, g * 16 + t * 4 + r])
-    assert np.array_equal(q[64 + 1 * 16 + 0 * 4 + 1, :5], w[0, 0, :, 64 + 0 * 16 + 1 * 4 + 1])
+    # layout 1: inside each group of 32 rows, packed row (r&3) + 8*(r>>2) + 4*h <- cout 16*h + r
+    for (h, r) in [(0, 0), (1, 0), (0, 5), (1, 15), (0, 10)]:
+        assert np.array_equal(q[(r & 3) + 8 * (r >> 2) + 4 * h, :5], w[0, 0, :, 16 * h + r])
+    assert np.array_equal(q[64 + (5 & 3) + 8 * (5 >> 2) + 4 * 0, :5], w[0, 0, :, 64 + 5])
 
 
 def test_pack_deconv_phases_reproduce_transposed_conv():

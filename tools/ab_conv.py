@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""In-process A/B timing of fn2_conv2d variants (cdna guide rule 24: interleaved rounds, one
+process, one device).  Variants are FN2_CONV_DBG bit sets (see conv2.hip): 8 flips the DMA
+interleave choice, 16 selects the direct epilogue; 1/2/4 are ablations (wrong results).
+
+  python tools/ab_conv.py --dtype bf16 --variants 0,8,16 --rounds 30
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flownet2-tf_amd"))
+from src import _hip, weights as W  # noqa: E402
+
+LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch 8 at 512x384
+    "conv2": ("conv", 5, 2, 2, 64, 128, 8, 192, 256),
+    "conv3": ("conv", 5, 2, 2, 128, 256, 8, 96, 128),
+    "conv3_1": ("conv", 3, 1, 1, 256, 256, 8, 48, 64),
+    "conv4_1": ("conv", 3, 1, 1, 512, 512, 8, 24, 32),
+    "conv6_1": ("conv", 3, 1, 1, 1024, 1024, 8, 6, 8),
+    "deconv3": ("deconv", 4, 2, 1, 770, 128, 8, 24, 32),
+    "deconv2": ("deconv", 4, 2, 1, 386, 64, 8, 48, 64),
+}
+
+
+def build(name, dtype):
+    kind, k, stride, pad, cin, cout, N, H, Wd = LAYERS[name]
+    lib = _hip.lib()
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    code = 0 if dtype == "f32" else 1
+    rng = np.random.default_rng(0)
+    cs_in = (cin + 63) // 64 * 64
+    x = torch.zeros((N, H, Wd, cs_in), dtype=td, device="cuda")
+    x[..., :cin] = torch.from_numpy(rng.standard_normal((N, H, Wd, cin)).astype(np.float32)).cuda().to(td)
+    if kind == "conv":
+        w = rng.standard_normal((k, k, cin, cout)).astype(np.float32) * 0.05
+        oh, ow = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
+    else:
+        w = rng.standard_normal((4, 4, cout, cin)).astype(np.float32) * 0.05
+        oh, ow = 2 * H, 2 * Wd
+    tile = lib.fn2_conv2d_cout_tile(cout)
+    cin_pad = cs_in if lib.fn2_conv2d_weight_layout(code, cs_in, cout) == 1 else (cin + 7) // 8 * 8
+    layout = lib.fn2_conv2d_weight_layout(code, cin_pad, cout)
+    pack = W.pack_conv if kind == "conv" else W.pack_deconv
+    packed, cin_pad, cout_pad, kpad = pack(w, tile, 32 if dtype == "bf16" else 16, cin_pad, layout)
+    wdev = torch.from_numpy(packed).cuda().to(td).contiguous()
+    out = torch.zeros((N, oh, ow, (cout + 63) // 64 * 64), dtype=td, device="cuda")
+    d = _hip.Fn2ConvDesc()
+    d.inp, d.out = _hip.view(x, cin, 0), _hip.view(out, cout, 0)
+    d.wgt, d.bias = wdev.data_ptr(), None
+    d.kind = 0 if kind == "conv" else 1
+    d.kh = d.kw = k
+    d.stride, d.pad, d.act = stride, pad, 1
+    d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, layout
+    need = int(lib.fn2_conv2d_workspace_bytes(C.byref(d)))
+    ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device="cuda")
+    if need:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    taps = k * k if kind == "conv" else 4
+    flop = 2.0 * N * oh * ow * taps * cin * cout
+    return d, flop, (x, wdev, out, ws)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--variants", default="0,16")
+    ap.add_argument("--layers", default=",".join(LAYERS))
+    ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--inner", type=int, default=5)
+    a = ap.parse_args()
+    lib = _hip.lib()
+    variants = [v for v in a.variants.split(",")]
+    for name in a.layers.split(","):
+        d, flop, keep = build(name, a.dtype)
+        times = {v: [] for v in variants}
+        s = _hip.stream_ptr()
+        for r in range(a.rounds + 2):
+            for v in variants:
+                os.environ["FN2_CONV_DBG"] = v
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.inner):
+                    _hip.check(lib.fn2_conv2d(C.byref(d), s))
+                e1.record()
+                torch.cuda.synchronize()
+                if r >= 2:
+                    times[v].append(e0.elapsed_time(e1) / a.inner)
+        line = "%-8s %-5s" % (name, a.dtype)
+        for v in variants:
+            t = np.array(times[v])
+            line += " | dbg=%-3s med %.4f min %.4f ms %7.1f TF" % (v, np.median(t), t.min(), flop / np.median(t) / 1e9)
+        print(line, flush=True)
+    os.environ.pop("FN2_CONV_DBG", None)
+
+
+if __name__ == "__main__":
+    main()
