@@ -161,8 +161,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
       for (int t = 0; t < TC; ++t)
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt)
-          acc[t][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]),
-                                                              __builtin_bit_cast(bf16x8, fb[pt]), acc[t][pt], 0, 0, 0);
+          acc[t][pt] = mfma_16x16x32<T>(fa[t], fb[pt], acc[t][pt]);
     } else {
       // independent accumulators back to back (fp32 MFMA: 40-cycle dependent latency, 32-cycle issue)
 #pragma unroll
@@ -299,6 +298,18 @@ __device__ __forceinline__ void dot_chunk<bf16_t>(const uint4& x, const uint4& w
   }
 }
 
+template <>
+__device__ __forceinline__ void dot_chunk<f16_t>(const uint4& x, const uint4& w0, const uint4& w1, float& a0,
+                                                 float& a1) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+  const h8 xv = __builtin_bit_cast(h8, x), u = __builtin_bit_cast(h8, w0), v = __builtin_bit_cast(h8, w1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a0 += (float)xv[j] * (float)u[j];
+    a1 += (float)xv[j] * (float)v[j];
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) flow_head_kernel(const ConvArgs p) {
   constexpr int CH = 16 / (int)sizeof(T);
@@ -417,7 +428,7 @@ static inline int grid_for(long work_items, int block) {
 
 static int check_view(const fn2_tensor* t, const char* what) {
   FN2_REQUIRE(t && t->data, "%s: null tensor", what);
-  FN2_REQUIRE(t->dtype == FN2_F32 || t->dtype == FN2_BF16, "%s: bad dtype", what);
+  FN2_REQUIRE(t->dtype == FN2_F32 || t->dtype == FN2_BF16 || t->dtype == FN2_F16, "%s: bad dtype", what);
   FN2_REQUIRE(t->n >= 1 && t->h >= 1 && t->w >= 1 && t->c >= 1, "%s: bad dims", what);
   FN2_REQUIRE(t->c0 >= 0 && t->c0 + t->c <= t->cs, "%s: channel slice outside the buffer", what);
   return FN2_OK;
@@ -453,7 +464,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cin_pad >= d->in.c, "conv2d: cin_pad must be a multiple of 8 >= Cin");
   FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: input channel stride/offset must be multiples of 8");
   FN2_REQUIRE(d->in.c0 + d->cin_pad <= d->in.cs, "conv2d: padded input channels exceed the buffer stride");
-  const int esz = d->in.dtype == FN2_BF16 ? 2 : 4;
+  const int esz = dtype_size(d->in.dtype);
   const int CH = 16 / esz;
   FN2_REQUIRE(d->kpad > 0 && d->kpad % (4 * CH) == 0, "conv2d: kpad must be a multiple of one k-step");
   const int tile = fn2_conv2d_cout_tile(d->out.c);
@@ -558,8 +569,10 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     const int blocks = grid_for((long)a.M * 64, 256);
     if (d->in.dtype == FN2_F32)
       hipLaunchKernelGGL(flow_head_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
-    else
+    else if (d->in.dtype == FN2_BF16)
       hipLaunchKernelGGL(flow_head_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(flow_head_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, a);
     FN2_CHECK_LAUNCH("flow_head");
     return FN2_OK;
   }
@@ -581,16 +594,21 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     if (a.splitk == 1) a.ws = nullptr;
     rc = launch_conv_fast(a, d->in.dtype, d->out.dtype, tile, phases, s);
   } else if (d->in.dtype == FN2_F32) rc = launch_conv<float, float>(a, tile, phases, s);
-  else if (d->out.dtype == FN2_BF16) rc = launch_conv<bf16_t, bf16_t>(a, tile, phases, s);
-  else rc = launch_conv<bf16_t, float>(a, tile, phases, s);
+  else if (d->in.dtype == FN2_BF16 && d->out.dtype == FN2_BF16) rc = launch_conv<bf16_t, bf16_t>(a, tile, phases, s);
+  else if (d->in.dtype == FN2_BF16) rc = launch_conv<bf16_t, float>(a, tile, phases, s);
+  else if (d->out.dtype == FN2_F16) rc = launch_conv<f16_t, f16_t>(a, tile, phases, s);
+  else rc = launch_conv<f16_t, float>(a, tile, phases, s);
   if (rc || a.splitk == 1) return rc;
   const long npix = (long)a.N * a.out_H * a.out_W;
   const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
   if (d->out.dtype == FN2_F32)
     hipLaunchKernelGGL(splitk_finalize_kernel<float>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (float*)a.out, npix,
                        a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
-  else
+  else if (d->out.dtype == FN2_BF16)
     hipLaunchKernelGGL(splitk_finalize_kernel<bf16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (bf16_t*)a.out,
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
+  else
+    hipLaunchKernelGGL(splitk_finalize_kernel<f16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (f16_t*)a.out,
                        npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
   FN2_CHECK_LAUNCH("splitk_finalize");
   return FN2_OK;
@@ -607,9 +625,12 @@ int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, in
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(upsample_flow_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        in, w, (float*)out->data, n, h, wd, out->cs, out->c0);
-  else
+  else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(upsample_flow_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        in, w, (bf16_t*)out->data, n, h, wd, out->cs, out->c0);
+  else
+    hipLaunchKernelGGL(upsample_flow_kernel<f16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, w, (f16_t*)out->data, n, h, wd, out->cs, out->c0);
   FN2_CHECK_LAUNCH("upsample_flow");
   return FN2_OK;
 }
@@ -619,9 +640,12 @@ static int pack_one(const float* img, const fn2_tensor* out, int n, int n0, int 
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(pack_image_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img,
                        (float*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
-  else
+  else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
                        img, (bf16_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+  else
+    hipLaunchKernelGGL(pack_image_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       img, (f16_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
   FN2_CHECK_LAUNCH("pack_image");
   return FN2_OK;
 }

@@ -33,28 +33,8 @@
 namespace fn2 {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr unsigned kOobOffset = 0x80000000u;  // >= num_records of every descriptor (tensors < 2 GiB)
-
-template <typename OutT>
-__device__ __forceinline__ void store16v(OutT* p, const float* v);
-template <>
-__device__ __forceinline__ void store16v<float>(float* p, const float* v) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    reinterpret_cast<float4*>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-template <>
-__device__ __forceinline__ void store16v<bf16_t>(bf16_t* p, const float* v) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    bf16x8 t;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[8 * q + j];
-    reinterpret_cast<bf16x8*>(p)[q] = t;
-  }
-}
 
 template <typename T, typename OutT, int WC, int WP>
 __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
@@ -199,9 +179,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
         for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
           for (int tp = 0; tp < 2; ++tp)
-            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][tc]),
-                                                                  __builtin_bit_cast(bf16x8, fb[cur][tp]),
-                                                                  acc[tc][tp], 0, 0, 0);
+            acc[tc][tp] = mfma_32x32x16<T>(fa[cur][tc], fb[cur][tp], acc[tc][tp]);
       } else {
         // chunk = 4 floats; MFMA j takes element j of both operands (a permutation of k shared by both)
 #pragma unroll
@@ -267,7 +245,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
         v[q] = x;
       }
       if (vec16 && cout_base + 15 < p.Cout) {
-        store16v<OutT>(po, v);
+        store16<OutT>(po, v);
       } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
@@ -294,15 +272,19 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
 }
 
 bool conv_fast_ok(int in_dtype, int cin_pad, int cout) {
-  const int esz = in_dtype == FN2_BF16 ? 2 : 4;
+  const int esz = dtype_size(in_dtype);
   return cout > 32 && (cin_pad * esz) % 128 == 0;
 }
 
 int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s) {
   if (tile != 128 && tile != 64) return fail(FN2_ERR_UNSUPPORTED, "conv fast path: cout tile %d", tile);
   if (in_dtype == FN2_F32) return launch2<float, float>(a, tile, phases, s);
-  if (out_dtype == FN2_BF16) return launch2<bf16_t, bf16_t>(a, tile, phases, s);
-  return launch2<bf16_t, float>(a, tile, phases, s);
+  if (in_dtype == FN2_BF16) {
+    if (out_dtype == FN2_BF16) return launch2<bf16_t, bf16_t>(a, tile, phases, s);
+    return launch2<bf16_t, float>(a, tile, phases, s);
+  }
+  if (out_dtype == FN2_F16) return launch2<f16_t, f16_t>(a, tile, phases, s);
+  return launch2<f16_t, float>(a, tile, phases, s);
 }
 
 }  // namespace fn2

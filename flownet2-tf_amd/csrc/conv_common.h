@@ -4,9 +4,6 @@
 
 namespace fn2 {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
 struct ConvArgs {
   const void* in;
   const void* wgt;
@@ -32,18 +29,10 @@ struct ConvArgs {
 };
 
 template <typename OutT>
-__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
-template <>
-__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d) {
+  const float v[4] = {a, b, c, d};
+  store_vec<OutT, 4>(p, v);
 }
-template <>
-__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-  bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
-  *reinterpret_cast<bf16x4*>(p) = v;
-}
-
 
 // conv2.hip: the fast path.  Returns FN2_ERR_UNSUPPORTED when (dtype, tile) has no instantiation.
 int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s);

@@ -17,8 +17,6 @@
 
 namespace fn2 {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 int correlation_geometry(int h, int w, int k, int md, int s1, int s2, int pad, int* oh, int* ow, int* gr,
                          int* gw);
@@ -143,8 +141,7 @@ __global__ void __launch_bounds__(256) corr_mfma_kernel(const CorrArgs p) {
         uint4 fb = make_uint4(0, 0, 0, 0);
         if (tile < CORR_WIN) fb = lds[buf][s][(tile * 16 + fi) * 4 + fchunk];
         if constexpr (sizeof(T) == 2) {
-          acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa),
-                                                           __builtin_bit_cast(bf16x8, fb), acc[tb], 0, 0, 0);
+          acc[tb] = mfma_16x16x32<T>(fa, fb, acc[tb]);
         } else {
           const float4 va = __builtin_bit_cast(float4, fa), vb = __builtin_bit_cast(float4, fb);
           acc[tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc[tb], 0, 0, 0);
@@ -253,7 +250,7 @@ int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_te
   FN2_REQUIRE(out->c == gw * gw, "correlation_fused: output view must have %d channels", gw * gw);
   FN2_REQUIRE(out->c0 + out->c <= out->cs && a->c0 + a->c <= a->cs && b->c0 + b->c <= b->cs,
               "correlation_fused: channel slice outside the buffer");
-  const int esz = a->dtype == FN2_BF16 ? 2 : 4;
+  const int esz = dtype_size(a->dtype);
   FN2_REQUIRE((a->cs * esz) % 16 == 0 && (a->c0 * esz) % 16 == 0 && (b->cs * esz) % 16 == 0 &&
                   (b->c0 * esz) % 16 == 0,
               "correlation_fused: feature views must be 16-byte aligned");
@@ -269,8 +266,12 @@ int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_te
   g.c_f = (float)a->c;
   hipStream_t s = (hipStream_t)stream;
   if (a->dtype == FN2_F32) return launch_corr<float, float>(g, a->c, s);
-  if (out->dtype == FN2_BF16) return launch_corr<bf16_t, bf16_t>(g, a->c, s);
-  return launch_corr<bf16_t, float>(g, a->c, s);
+  if (a->dtype == FN2_BF16) {
+    if (out->dtype == FN2_BF16) return launch_corr<bf16_t, bf16_t>(g, a->c, s);
+    return launch_corr<bf16_t, float>(g, a->c, s);
+  }
+  if (out->dtype == FN2_F16) return launch_corr<f16_t, f16_t>(g, a->c, s);
+  return launch_corr<f16_t, float>(g, a->c, s);
 }
 
 }  // extern "C"

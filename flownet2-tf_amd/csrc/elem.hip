@@ -26,26 +26,6 @@ __device__ __forceinline__ void warp3(const float* __restrict__ img, long nb, in
 }
 
 template <typename OutT>
-__device__ __forceinline__ void store16(OutT* dst, const float v[16]);
-template <>
-__device__ __forceinline__ void store16<float>(float* dst, const float v[16]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-template <>
-__device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float v[16]) {
-  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    bf16x8 t;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[8 * q + j];
-    reinterpret_cast<bf16x8*>(dst)[q] = t;
-  }
-}
-
-template <typename OutT>
 __global__ void __launch_bounds__(256) stack_input_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           const float* __restrict__ flow, OutT* __restrict__ out,
                                                           int N, int H, int W, int out_cs, int out_c0) {
@@ -121,7 +101,7 @@ static int check_out16(const fn2_tensor* out, int c, const char* what) {
   FN2_REQUIRE(out->c == c, "%s: output view must have %d channels", what, c);
   FN2_REQUIRE(out->cs % 8 == 0 && out->c0 % 8 == 0 && out->c0 + 16 <= out->cs,
               "%s: output needs a 16-channel, 8-aligned slot", what);
-  FN2_REQUIRE(out->dtype == FN2_F32 || out->dtype == FN2_BF16, "%s: bad dtype", what);
+  FN2_REQUIRE(out->dtype == FN2_F32 || out->dtype == FN2_BF16 || out->dtype == FN2_F16, "%s: bad dtype", what);
   return FN2_OK;
 }
 
@@ -139,9 +119,12 @@ int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(stack_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        b, flow, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
-  else
+  else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(stack_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        b, flow, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  else
+    hipLaunchKernelGGL(stack_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, flow, (f16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
   FN2_CHECK_LAUNCH("stack_input");
   return FN2_OK;
 }
@@ -155,9 +138,12 @@ int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(fusion_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        b, flow_sd, flow_css, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
-  else
+  else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(fusion_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
                        a, b, flow_sd, flow_css, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  else
+    hipLaunchKernelGGL(fusion_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, flow_sd, flow_css, (f16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
   FN2_CHECK_LAUNCH("fusion_input");
   return FN2_OK;
 }

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libflownet2_hip.so")
 
-FN2_F32, FN2_BF16 = 0, 1
+FN2_F32, FN2_BF16, FN2_F16 = 0, 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3
@@ -118,6 +118,8 @@ def dtype_code(t):
         return FN2_F32
     if t.dtype == torch.bfloat16:
         return FN2_BF16
+    if t.dtype == torch.float16:
+        return FN2_F16
     raise ValueError("unsupported dtype %s" % t.dtype)
 
 

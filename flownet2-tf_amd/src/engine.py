@@ -14,8 +14,8 @@ over preallocated NHWC activation buffers:
   * the plan can be captured once into a hipGraph (``capture()``) and replayed.
 
 torch is only the device-memory container (buffers, streams).  dtype "f32" runs
-the fp32 MFMA parity path, "bf16" the bf16 MFMA throughput path (activations and
-weights bf16, fp32 accumulate, flow heads / warps / resize in fp32).
+the fp32 MFMA parity path; "bf16" / "f16" the 16-bit MFMA throughput paths (activations and
+weights 16-bit, fp32 accumulate, flow heads / warps / resize in fp32).
 """
 import ctypes as C
 
@@ -23,7 +23,9 @@ import torch
 
 from . import _hip, netdefs, weights as W
 
-_DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+_CODE = {"f32": _hip.FN2_F32, "bf16": _hip.FN2_BF16, "f16": _hip.FN2_F16}
+_TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16"}
 
 
 def _round_up(x, m):
@@ -35,14 +37,14 @@ class Engine:
         if model not in netdefs.MODELS:
             raise ValueError("unknown model %r" % model)
         if dtype not in _DT:
-            raise ValueError("dtype must be 'f32' or 'bf16'")
+            raise ValueError("dtype must be 'f32', 'bf16' or 'f16'")
         if height % 64 or width % 64:
             raise ValueError("height and width must be multiples of 64 (pad with Net.adapt_x, net.py:373-388)")
         self.lib = _hip.lib()
         self.device = device if device is not None else _hip.require_device()
         self.model, self.N, self.H, self.W = model, int(batch), int(height), int(width)
         self.dtype_name, self.tdtype = dtype, _DT[dtype]
-        self.kstep = 32 if dtype == "bf16" else 16
+        self.kstep = 16 if dtype == "f32" else 32
         self.weights = weights
         self.ops = []      # (name, fn, args) ; args exclude the trailing stream
         self.kernel_of = []  # per op: the device kernel (template instantiation) that does the work
@@ -83,7 +85,7 @@ class Engine:
         assert sc == cin and dc == cout, (scope, name, sc, cin, dc, cout)
         tile = self.lib.fn2_conv2d_cout_tile(cout)
         wname = f"{scope}/{name}/weights"
-        dt_code = _hip.FN2_BF16 if self.dtype_name == "bf16" else _hip.FN2_F32
+        dt_code = _CODE[self.dtype_name]
         cin_pad = _round_up(cin, 8)
         cin64 = _round_up(cin, 64)
         if cin > 32 and sc0 + cin64 <= sbuf.shape[3] and self.lib.fn2_conv2d_weight_layout(dt_code, cin64, cout) == 1:
@@ -109,7 +111,7 @@ class Engine:
         d.wgt_layout = layout
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
-        tn = "__bf16" if self.dtype_name == "bf16" else "float"
+        tn = _TNAME[self.dtype_name]
         if kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1:
             kern = f"flow_head_kernel<{tn}>"
         elif layout == 1:
@@ -234,9 +236,9 @@ class Engine:
         net = self._buf(f"{tag}/corr_concat", N, H // 8, W_ // 8, 473)  # [conv_redir(32) | corr(441)], :46
         va, vb, vo = self._v(c3a, 256, 0), self._v(c3b, 256, 0), self._v(net, 441, 32)
         self.keep += [va, vb, vo]
-        tn = "__bf16" if self.dtype_name == "bf16" else "float"
+        tn = _TNAME[self.dtype_name]
         self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
-                 _hip.ACT_LEAKY, kernel=f"corr_mfma_kernel<{tn}, {tn}, {8 if self.dtype_name == 'bf16' else 16}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
+                 _hip.ACT_LEAKY, kernel=f"corr_mfma_kernel<{tn}, {tn}, {16 if self.dtype_name == 'f32' else 8}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
         self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
         self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
         self._conv(scope, L["conv3_1"], (net, 0, 473), (cats[3], 0, 256))

@@ -57,7 +57,7 @@ typedef enum {
   FN2_ERR_HIP = -3               /* a HIP runtime call or kernel launch failed */
 } fn2_status;
 
-typedef enum { FN2_F32 = 0, FN2_BF16 = 1 } fn2_dtype;
+typedef enum { FN2_F32 = 0, FN2_BF16 = 1, FN2_F16 = 2 } fn2_dtype;
 
 typedef enum { FN2_ACT_NONE = 0, FN2_ACT_LEAKY = 1 /* 0.55x + 0.45|x|, utils.py:401-405 */ } fn2_act;
 

@@ -98,6 +98,18 @@ def test_bf16_path_bounded(model):
     assert e < 0.05 * mag
 
 
+@pytest.mark.parametrize("model", ["FlowNetS", "FlowNetC", "FlowNet2"])
+def test_f16_path_reported(model):
+    """fp16 activations/weights (11 mantissa bits), fp32 accumulate: measured against the oracle and
+    printed; asserted only against a loose sanity bound -- the 1e-3 px bar is the f32 path's."""
+    n, h, w = (1, 64, 64) if model == "FlowNet2" else (2, 64, 128)
+    out, want = run(model, "f16", n, h, w)
+    e = epe(out["flow"], want["flow"])
+    mag = float(np.sqrt((want["flow"] ** 2).sum(-1)).mean())
+    print(model, "f16 mean EPE vs oracle %.3e px (mean |flow| %.2f px)" % (e, mag))
+    assert e < 0.01 * max(mag, 0.1)
+
+
 def test_graph_replay_equals_eager():
     from src import weights as W
     from src.engine import Engine

@@ -31,8 +31,8 @@ LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch
 def build(name, dtype):
     kind, k, stride, pad, cin, cout, N, H, Wd = LAYERS[name]
     lib = _hip.lib()
-    td = torch.float32 if dtype == "f32" else torch.bfloat16
-    code = 0 if dtype == "f32" else 1
+    td = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    code = {"f32": 0, "bf16": 1, "f16": 2}[dtype]
     rng = np.random.default_rng(0)
     cs_in = (cin + 63) // 64 * 64
     x = torch.zeros((N, H, Wd, cs_in), dtype=td, device="cuda")
@@ -47,7 +47,7 @@ def build(name, dtype):
     cin_pad = cs_in if lib.fn2_conv2d_weight_layout(code, cs_in, cout) == 1 else (cin + 7) // 8 * 8
     layout = lib.fn2_conv2d_weight_layout(code, cin_pad, cout)
     pack = W.pack_conv if kind == "conv" else W.pack_deconv
-    packed, cin_pad, cout_pad, kpad = pack(w, tile, 32 if dtype == "bf16" else 16, cin_pad, layout)
+    packed, cin_pad, cout_pad, kpad = pack(w, tile, 16 if dtype == "f32" else 32, cin_pad, layout)
     wdev = torch.from_numpy(packed).cuda().to(td).contiguous()
     out = torch.zeros((N, oh, ow, (cout + 63) // 64 * 64), dtype=td, device="cuda")
     d = _hip.Fn2ConvDesc()
