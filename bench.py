@@ -39,6 +39,21 @@ def synth_pairs(n, h, w, seed0):
     return np.stack(a_l).astype(np.float32), np.stack(b_l).astype(np.float32)
 
 
+def stored_traffic(model, batch, dtype, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes).  PMC collection
+    cannot run inside this process, so the number is read from profiles/ and is null when no pass
+    exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_%s_b%d_%s.json" % (model, batch, dtype))
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    for k, v in table.items():
+        if kernel in k:
+            return round(v["hbm_bytes_per_launch"])
+    return None
+
+
 def per_kernel_times(eng, steps):
     """Eager pass with an event pair around every launch on the launch stream."""
     n_ops = len(eng.ops)
@@ -166,7 +181,9 @@ def main():
         achieved = (D["flop"] / D["launches"]) / (avg_ms * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
+                    "traffic": stored_traffic(args.model, args.batch, args.dtype, dom) if
+                    (args.height, args.width) == (384, 512) else None,
                     "launches_per_step": D["launches"], "avg_launch_ms": round(avg_ms, 5),
                     "flop_per_launch": D["flop"] / D["launches"]}
         kernels = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"]} for k, v in fams.items()}
