@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "flownet2-tf_amd"))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # dense MFMA peaks, MI355X_MICROARCH.md
+# f16x2: 3 fp16 MFMAs per algorithmic product -> the algorithmic peak is a third of the fp16 peak
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f16x2": 2500.0 / 3}  # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 K80_MS = {"FlowNetS": 38.067, "FlowNetC": 78.789, "FlowNetCS": 123.300, "FlowNetCSS": 161.186,
           "FlowNetSD": 62.061, "FlowNet2": 276.641}  # reference README.md:71 (other hardware)
@@ -107,7 +108,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "f16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch ms and TFLOP/s to stderr")

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = acc[t][pt][r] + bias[t][r];
+        float x = acc[t][pt][r] * p.out_scale + bias[t][r];
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
         v[r] = x;
       }
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < p.Cout) po[co + r] = from_f32<OutT>(v[r]);
+          if (co + r < p.Cout) store_elem<OutT>(po + co + r, v[r]);
       }
     }
   }
@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 template <typename OutT>
 __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                               OutT* __restrict__ out, long npix, int ws_cs, int splitk,
-                                                              int Cout, int out_cs, int out_c0, int act, int vec_ok) {
+                                                              int Cout, int out_cs, int out_c0, int act, int vec_ok,
+                                                              float out_scale) {
   const int groups = ws_cs / 4;
   const long total = npix * groups;
   const size_t slab = (size_t)npix * ws_cs;
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      r[j] *= out_scale;
       if (bias != nullptr && co + j < Cout) r[j] += bias[co + j];
       if (act == FN2_ACT_LEAKY) r[j] = leaky(r[j]);
     }
@@ -266,7 +268,7 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (co + j < Cout) po[j] = from_f32<OutT>(r[j]);
+        if (co + j < Cout) store_elem<OutT>(po + j, r[j]);
     }
   }
 }
@@ -299,6 +301,8 @@ __device__ __forceinline__ void dot_chunk<bf16_t>(const uint4& x, const uint4& w
 }
 
 template <>
+__device__ __forceinline__ void dot_chunk<x2_t>(const uint4&, const uint4&, const uint4&, float&, float&) {}
+template <>
 __device__ __forceinline__ void dot_chunk<f16_t>(const uint4& x, const uint4& w0, const uint4& w1, float& a0,
                                                  float& a1) {
   typedef __attribute__((ext_vector_type(8))) _Float16 h8;
@@ -320,6 +324,45 @@ __global__ void __launch_bounds__(256) flow_head_kernel(const ConvArgs p) {
   const T* w0 = reinterpret_cast<const T*>(p.wgt);
   const T* w1 = w0 + (size_t)p.ksteps * 4 * CH;
   float* out = reinterpret_cast<float*>(p.out);
+  if constexpr (is_x2<T>::value) {
+    // split-fp16 activations, fp32 weights: an item is one group of 8 channels of one tap
+    const float* wf0 = reinterpret_cast<const float*>(p.wgt);
+    const float* wf1 = wf0 + (size_t)p.ksteps * 4 * CH;
+    const int groups = p.cin_chunks >> 1;
+    const int nitems = 9 * groups;
+    for (long m = wave; m < p.M; m += nwaves) {
+      const int x = (int)(m % p.W), y = (int)((m / p.W) % p.H);
+      const size_t nb = (size_t)(m / p.W / p.H) * p.H * p.W;
+      float a0 = 0.f, a1 = 0.f;
+      for (int q = lane; q < nitems; q += 64) {
+        const int tap = q / groups, gi = q - tap * groups;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = y + ky - 1, ix = x + kx - 1;
+        if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+        const uint4* src = reinterpret_cast<const uint4*>(in + (nb + (size_t)iy * p.W + ix) * p.in_cs + p.in_c0 + gi * 8);
+        float xv[8];
+        join8(src[0], src[1], xv);
+        const float* u = wf0 + (size_t)q * 8;
+        const float* v = wf1 + (size_t)q * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          a0 += xv[j] * u[j];
+          a1 += xv[j] * v[j];
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off, 64);
+        a1 += __shfl_xor(a1, off, 64);
+      }
+      if (lane == 0) {
+        float* po = out + (size_t)m * p.out_cs + p.out_c0;
+        po[0] = a0 * p.out_scale + (p.bias ? p.bias[0] : 0.f);
+        po[1] = a1 * p.out_scale + (p.bias ? p.bias[1] : 0.f);
+      }
+    }
+    return;
+  }
   const int items = 9 * p.cin_chunks;
   for (long m = wave; m < p.M; m += nwaves) {
     const int x = (int)(m % p.W), y = (int)((m / p.W) % p.H);
@@ -341,8 +384,8 @@ __global__ void __launch_bounds__(256) flow_head_kernel(const ConvArgs p) {
     }
     if (lane == 0) {
       float* po = out + (size_t)m * p.out_cs + p.out_c0;
-      po[0] = a0 + (p.bias ? p.bias[0] : 0.f);
-      po[1] = a1 + (p.bias ? p.bias[1] : 0.f);
+      po[0] = a0 * p.out_scale + (p.bias ? p.bias[0] : 0.f);
+      po[1] = a1 * p.out_scale + (p.bias ? p.bias[1] : 0.f);
     }
   }
 }
@@ -401,8 +444,8 @@ __global__ void __launch_bounds__(256) upsample_flow_kernel(const float* __restr
       }
     }
     OutT* po = out + (size_t)o * out_cs + out_c0;
-    po[0] = from_f32<OutT>(r0);
-    po[1] = from_f32<OutT>(r1);
+    store_elem<OutT>(po, r0);
+    store_elem<OutT>(po + 1, r1);
   }
 }
 
@@ -413,9 +456,9 @@ __global__ void __launch_bounds__(256) pack_image_kernel(const float* __restrict
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
     const float* s = img + i * 3;
     OutT* d = out + (size_t)(pix0 + i) * out_cs + c_dst;
-    d[0] = from_f32<OutT>(s[0]);
-    d[1] = from_f32<OutT>(s[1]);
-    d[2] = from_f32<OutT>(s[2]);
+    store_elem<OutT>(d, s[0]);
+    store_elem<OutT>(d + 1, s[1]);
+    store_elem<OutT>(d + 2, s[2]);
   }
 }
 
@@ -428,7 +471,7 @@ static inline int grid_for(long work_items, int block) {
 
 static int check_view(const fn2_tensor* t, const char* what) {
   FN2_REQUIRE(t && t->data, "%s: null tensor", what);
-  FN2_REQUIRE(t->dtype == FN2_F32 || t->dtype == FN2_BF16 || t->dtype == FN2_F16, "%s: bad dtype", what);
+  FN2_REQUIRE(t->dtype >= FN2_F32 && t->dtype <= FN2_F16X2, "%s: bad dtype", what);
   FN2_REQUIRE(t->n >= 1 && t->h >= 1 && t->w >= 1 && t->c >= 1, "%s: bad dims", what);
   FN2_REQUIRE(t->c0 >= 0 && t->c0 + t->c <= t->cs, "%s: channel slice outside the buffer", what);
   return FN2_OK;
@@ -440,7 +483,27 @@ using namespace fn2;
 
 extern "C" {
 
-int fn2_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16; }
+int fn2_conv2d_plan(int in_dtype, int cin_pad, int cout, fn2_conv_plan* plan) {
+  FN2_REQUIRE(plan, "conv2d_plan: null plan");
+  FN2_REQUIRE(in_dtype >= FN2_F32 && in_dtype <= FN2_F16X2, "conv2d_plan: bad dtype");
+  FN2_REQUIRE(cin_pad > 0 && cin_pad % 8 == 0 && cout >= 1, "conv2d_plan: cin_pad must be a positive multiple of 8");
+  const int esz = dtype_size(in_dtype);
+  if (cout == 2) {  // flow heads: dedicated dot-product kernel reading rows 0 and 1 of a natural-order weight
+    plan->layout = 0; plan->cout_tile = 16; plan->kstep_elems = 64 / esz;
+    plan->wgt_dtype = in_dtype == FN2_F16X2 ? FN2_F32 : in_dtype;
+    return FN2_OK;
+  }
+  if (conv_fast_ok(in_dtype, cin_pad, cout)) {
+    plan->layout = 1; plan->cout_tile = cout > 64 ? 128 : 64; plan->kstep_elems = 128 / esz;
+    plan->wgt_dtype = in_dtype;
+    return FN2_OK;
+  }
+  if (in_dtype == FN2_F16X2)
+    return fail(FN2_ERR_UNSUPPORTED, "split-fp16 inputs need cin_pad %% 32 == 0 (LDS-DMA kernel); got %d", cin_pad);
+  plan->layout = 0; plan->cout_tile = cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16;
+  plan->kstep_elems = 64 / esz; plan->wgt_dtype = in_dtype;
+  return FN2_OK;
+}
 
 }  // extern "C"
 
@@ -450,6 +513,7 @@ static bool is_flow_head(const fn2_conv_desc* d) {
   return d->kind == 0 && d->out.c == 2 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
          d->out.dtype == FN2_F32 && d->act == FN2_ACT_NONE;
 }
+// Cout == 2 layers that are not 3x3/s1/p1 fp32-out heads run on the generic kernel (16-cout tile)
 
 // validate + fill everything except the split-K fields
 static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int* phases_out) {
@@ -467,10 +531,19 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   const int esz = dtype_size(d->in.dtype);
   const int CH = 16 / esz;
   FN2_REQUIRE(d->kpad > 0 && d->kpad % (4 * CH) == 0, "conv2d: kpad must be a multiple of one k-step");
-  const int tile = fn2_conv2d_cout_tile(d->out.c);
+  fn2_conv_plan plan;
+  rc = fn2_conv2d_plan(d->in.dtype, d->cin_pad, d->out.c, &plan);
+  if (rc) return rc;
+  FN2_REQUIRE(d->wgt_layout == plan.layout, "conv2d: wgt_layout %d does not match fn2_conv2d_plan (%d)", d->wgt_layout,
+              plan.layout);
+  const int tile = plan.cout_tile;
   FN2_REQUIRE(d->cout_pad % tile == 0 && d->cout_pad >= d->out.c, "conv2d: cout_pad must be a multiple of the cout tile");
   FN2_REQUIRE(d->act == FN2_ACT_NONE || d->act == FN2_ACT_LEAKY, "conv2d: bad activation");
-  FN2_REQUIRE(d->out.dtype == d->in.dtype || d->out.dtype == FN2_F32, "conv2d: output dtype must be the input dtype or fp32");
+  FN2_REQUIRE(d->out.dtype == d->in.dtype || d->out.dtype == FN2_F32 ||
+                  (d->in.dtype == FN2_F32 && d->out.dtype == FN2_F16X2),
+              "conv2d: output dtype must be the input dtype, fp32, or split-fp16 from an fp32 stem");
+  if (d->in.dtype == FN2_F16X2) FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: split-fp16 views are group (8) aligned");
+  if (d->out.dtype == FN2_F16X2) FN2_REQUIRE(d->out.cs % 8 == 0 && d->out.c0 % 8 == 0, "conv2d: split-fp16 views are group (8) aligned");
 
   ConvArgs& a = *out;
   a.in = d->in.data; a.wgt = d->wgt; a.bias = d->bias; a.out = d->out.data;
@@ -503,10 +576,10 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   a.ksteps = d->kpad / (4 * CH);
   a.cout_pad = d->cout_pad;
   a.act = d->act;
+  a.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
   a.vec_ok = (d->out.cs % 4 == 0) && (d->out.c0 % 4 == 0);
   a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = (a.Cout + 3) / 4 * 4;
   { const char* e = getenv("FN2_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
-  FN2_REQUIRE(d->wgt_layout == 0 || d->wgt_layout == 1, "conv2d: bad wgt_layout");
   a.in_bytes = 0;
   if (d->wgt_layout == 1) {
     // the LDS-DMA kernel addresses both operands through buffer descriptors with 32-bit byte offsets
@@ -515,9 +588,6 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     FN2_REQUIRE((long)d->cout_pad * d->kpad * esz < (1L << 31), "conv2d: packed weight >= 2 GiB per phase");
     a.in_bytes = (int)in_bytes;
   }
-  if (d->wgt_layout == 1)
-    FN2_REQUIRE(conv_fast_ok(d->in.dtype, d->cin_pad, d->out.c) && !is_flow_head(d),
-                "conv2d: wgt_layout 1 given but this layer does not run on the LDS-DMA kernel");
   *tile_out = tile;
   *phases_out = phases;
   return FN2_OK;
@@ -546,10 +616,6 @@ static int64_t split_bytes(const ConvArgs& a, int s) {
 
 extern "C" {
 
-int fn2_conv2d_weight_layout(int in_dtype, int cin_pad, int cout) {
-  return (cout != 2 && conv_fast_ok(in_dtype, cin_pad, cout)) ? 1 : 0;
-}
-
 int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d) {
   ConvArgs a;
   int tile, phases;
@@ -571,8 +637,10 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
       hipLaunchKernelGGL(flow_head_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
     else if (d->in.dtype == FN2_BF16)
       hipLaunchKernelGGL(flow_head_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
-    else
+    else if (d->in.dtype == FN2_F16)
       hipLaunchKernelGGL(flow_head_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(flow_head_kernel<x2_t>, dim3(blocks), dim3(256), 0, s, a);
     FN2_CHECK_LAUNCH("flow_head");
     return FN2_OK;
   }
@@ -593,7 +661,8 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     a.splitk = cdiv(a.ksteps, a.kper);
     if (a.splitk == 1) a.ws = nullptr;
     rc = launch_conv_fast(a, d->in.dtype, d->out.dtype, tile, phases, s);
-  } else if (d->in.dtype == FN2_F32) rc = launch_conv<float, float>(a, tile, phases, s);
+  } else if (d->in.dtype == FN2_F32 && d->out.dtype == FN2_F16X2) rc = launch_conv<float, x2_t>(a, tile, phases, s);
+  else if (d->in.dtype == FN2_F32) rc = launch_conv<float, float>(a, tile, phases, s);
   else if (d->in.dtype == FN2_BF16 && d->out.dtype == FN2_BF16) rc = launch_conv<bf16_t, bf16_t>(a, tile, phases, s);
   else if (d->in.dtype == FN2_BF16) rc = launch_conv<bf16_t, float>(a, tile, phases, s);
   else if (d->out.dtype == FN2_F16) rc = launch_conv<f16_t, f16_t>(a, tile, phases, s);
@@ -603,13 +672,16 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
   if (d->out.dtype == FN2_F32)
     hipLaunchKernelGGL(splitk_finalize_kernel<float>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (float*)a.out, npix,
-                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
+                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
+  else if (d->out.dtype == FN2_F16X2)
+    hipLaunchKernelGGL(splitk_finalize_kernel<x2_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (x2_t*)a.out,
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
   else if (d->out.dtype == FN2_BF16)
     hipLaunchKernelGGL(splitk_finalize_kernel<bf16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (bf16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
   else
     hipLaunchKernelGGL(splitk_finalize_kernel<f16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (f16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
   FN2_CHECK_LAUNCH("splitk_finalize");
   return FN2_OK;
 }
@@ -625,6 +697,9 @@ int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, in
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(upsample_flow_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        in, w, (float*)out->data, n, h, wd, out->cs, out->c0);
+  else if (out->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(upsample_flow_kernel<x2_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, w, (x2_t*)out->data, n, h, wd, out->cs, out->c0);
   else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(upsample_flow_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        in, w, (bf16_t*)out->data, n, h, wd, out->cs, out->c0);
@@ -640,6 +715,9 @@ static int pack_one(const float* img, const fn2_tensor* out, int n, int n0, int 
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(pack_image_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img,
                        (float*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+  else if (out->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(pack_image_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       img, (x2_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
   else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
                        img, (bf16_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);

@@ -159,6 +159,32 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     if (s + 1 < kt1) issue_stage(buf ^ 1);  // next stage's DMA in flight under this stage's MFMAs
     const uint4* A = &lds[buf][(wc * 64 + fr) * 8];
     const uint4* B = &lds[buf][(BC + wp * 64 + fr) * 8];
+    if constexpr (is_x2<T>::value) {
+      // split fp16: the 128-byte row is [hi g0 | lo g0 | hi g1 | lo g1 | hi g2 | lo g2 | hi g3 | lo g3]
+      // (4 groups of 8 channels).  One 32x32x16 product covers groups (2q, 2q+1): lane half h owns
+      // group 2q+h, i.e. chunks 4q+2h (hi) and 4q+2h+1 (lo);  x*w = hi*hi + hi*lo + lo*hi.
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
+        uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ah[t] = A[t * 32 * 8 + chh]; al[t] = A[t * 32 * 8 + chl];
+          bh[t] = B[t * 32 * 8 + chh]; bl[t] = B[t * 32 * 8 + chl];
+        }
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp) {
+            acc[tc][tp] = mfma_32x32x16<f16_t>(al[tc], bh[tp], acc[tc][tp]);
+            acc[tc][tp] = mfma_32x32x16<f16_t>(ah[tc], bl[tp], acc[tc][tp]);
+            acc[tc][tp] = mfma_32x32x16<f16_t>(ah[tc], bh[tp], acc[tc][tp]);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
     // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
     uint4 fa[2][2], fb[2][2];
     {
@@ -240,7 +266,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       float v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        float x = acc[tc][tp][q] + bias[q];
+        float x = acc[tc][tp][q] * p.out_scale + bias[q];
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
         v[q] = x;
       }
@@ -249,7 +275,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-          if (cout_base + q < p.Cout) po[q] = from_f32<OutT>(v[q]);
+          if (cout_base + q < p.Cout) store_elem<OutT>(po + q, v[q]);
       }
     }
   }
@@ -273,7 +299,7 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
 
 bool conv_fast_ok(int in_dtype, int cin_pad, int cout) {
   const int esz = dtype_size(in_dtype);
-  return cout > 32 && (cin_pad * esz) % 128 == 0;
+  return cout > 2 && (cin_pad * esz) % 128 == 0;
 }
 
 int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s) {
@@ -283,8 +309,12 @@ int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, i
     if (out_dtype == FN2_BF16) return launch2<bf16_t, bf16_t>(a, tile, phases, s);
     return launch2<bf16_t, float>(a, tile, phases, s);
   }
-  if (out_dtype == FN2_F16) return launch2<f16_t, f16_t>(a, tile, phases, s);
-  return launch2<f16_t, float>(a, tile, phases, s);
+  if (in_dtype == FN2_F16) {
+    if (out_dtype == FN2_F16) return launch2<f16_t, f16_t>(a, tile, phases, s);
+    return launch2<f16_t, float>(a, tile, phases, s);
+  }
+  if (out_dtype == FN2_F16X2) return launch2<x2_t, x2_t>(a, tile, phases, s);
+  return launch2<x2_t, float>(a, tile, phases, s);
 }
 
 }  // namespace fn2

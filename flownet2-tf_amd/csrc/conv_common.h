@@ -24,6 +24,7 @@ struct ConvArgs {
   int kper;    // k-steps per split
   float* ws;   // [splitk][N*out_H*out_W][ws_cs] fp32 partial sums
   int ws_cs;   // Cout rounded up to 4
+  float out_scale;  // accumulator scale before bias (power of two chosen by the weight packer)
   int in_bytes;  // byte size of the input buffer (LDS-DMA kernel: buffer descriptor num_records)
   int dbg;     // FN2_CONV_DBG ablation bits (timing experiments only; results are wrong when set)
 };

@@ -58,10 +58,28 @@ __global__ void __launch_bounds__(256) corr_mfma_kernel(const CorrArgs p) {
   {
     const int x = xb + wave * 16 + fi;
     const bool ok = x < p.W;
-    const T* src = A + (((size_t)n * p.H + y) * p.W + (ok ? x : 0)) * p.a_cs + p.a_c0 + fg * CH;
+    if constexpr (is_x2<T>::value) {
+      // split fp16 -> fp32 operands: slab s = 16 channels = groups 2s, 2s+1; this lane's 4 channels
+      // are j0..j0+3 of group 2s + (fg>>1): 8 bytes of hi parts and 8 bytes of lo parts
+      const char* src = reinterpret_cast<const char*>(A + (((size_t)n * p.H + y) * p.W + (ok ? x : 0)) * p.a_cs + p.a_c0) +
+                        (fg >> 1) * 32 + (fg & 1) * 8;
+      typedef __attribute__((ext_vector_type(4))) _Float16 h4;
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-      afrag[s] = ok ? *reinterpret_cast<const uint4*>(src + s * 4 * CH) : make_uint4(0, 0, 0, 0);
+      for (int s = 0; s < NS; ++s) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          const h4 h = *reinterpret_cast<const h4*>(src + s * 64), l = *reinterpret_cast<const h4*>(src + s * 64 + 16);
+          v = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                          (float)h[3] + (float)l[3]);
+        }
+        afrag[s] = __builtin_bit_cast(uint4, v);
+      }
+    } else {
+      const T* src = A + (((size_t)n * p.H + y) * p.W + (ok ? x : 0)) * p.a_cs + p.a_c0 + fg * CH;
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        afrag[s] = ok ? *reinterpret_cast<const uint4*>(src + s * 4 * CH) : make_uint4(0, 0, 0, 0);
+    }
   }
 
   // valid displaced rows: yb = y + (pi - gr)*s2 in [0, H)
@@ -76,14 +94,38 @@ __global__ void __launch_bounds__(256) corr_mfma_kernel(const CorrArgs p) {
       const int px = idx / p.gw, o = idx - px * p.gw;
       const int x = xb + wave * 16 + px;
       if (x < p.W)
-        out[(((size_t)n * p.H + y) * p.W + x) * p.out_cs + p.out_c0 + pi * p.gw + o] = from_f32<OutT>(0.f);
+        store_elem<OutT>(out + (((size_t)n * p.H + y) * p.W + x) * p.out_cs + p.out_c0 + pi * p.gw + o, 0.f);
     }
   }
   const int niter = (p_hi - p_lo + 1) * NSTAGE;
   if (niter <= 0) return;
 
-  uint4 regs[NLD];
+  // split fp16: a work item is one (pixel, group of 8 channels) = 32 bytes in, two fp32 chunks out
+  constexpr int X2_ITEMS = WPX * SG * 2;
+  constexpr int NLD2 = (X2_ITEMS + 255) / 256;
+  uint4 regs[is_x2<T>::value ? 2 * NLD2 : NLD];
   auto load_stage = [&](int it) {
+    if constexpr (is_x2<T>::value) {
+      const int pi = p_lo + it / NSTAGE, st = it % NSTAGE;
+      const int yb = y + (pi - p.gr) * p.s2;
+      const T* rowb = B + ((size_t)n * p.H + yb) * p.W * p.b_cs + p.b_c0 + st * SG * 4 * CH;
+#pragma unroll
+      for (int q = 0; q < NLD2; ++q) {
+        const int e = tid + 256 * q;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (e < X2_ITEMS) {
+          const int px = e / (SG * 2), gi = e % (SG * 2);
+          const int xw = xb - p.md + px;
+          if (xw >= 0 && xw < p.W) {
+            const uint4* src = reinterpret_cast<const uint4*>(rowb + (size_t)xw * p.b_cs + gi * 8);
+            join8(src[0], src[1], v);
+          }
+        }
+        regs[2 * q] = __builtin_bit_cast(uint4, make_float4(v[0], v[1], v[2], v[3]));
+        regs[2 * q + 1] = __builtin_bit_cast(uint4, make_float4(v[4], v[5], v[6], v[7]));
+      }
+      return;
+    }
     const int pi = p_lo + it / NSTAGE, st = it % NSTAGE;
     const int yb = y + (pi - p.gr) * p.s2;
     const T* rowb = B + ((size_t)n * p.H + yb) * p.W * p.b_cs + p.b_c0 + st * SG * 4 * CH;
@@ -100,6 +142,19 @@ __global__ void __launch_bounds__(256) corr_mfma_kernel(const CorrArgs p) {
     }
   };
   auto store_stage = [&](int buf) {
+    if constexpr (is_x2<T>::value) {
+#pragma unroll
+      for (int q = 0; q < NLD2; ++q) {
+        const int e = tid + 256 * q;
+        if (e < X2_ITEMS) {
+          const int px = e / (SG * 2), gi = e % (SG * 2);
+          const int slab = gi >> 1, c0 = (gi & 1) * 2, sw = ((px >> 3) & 1) * 3;
+          lds[buf][slab][px * 4 + (c0 ^ sw)] = regs[2 * q];
+          lds[buf][slab][px * 4 + ((c0 + 1) ^ sw)] = regs[2 * q + 1];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
       const int e = tid + 256 * q;
@@ -165,8 +220,7 @@ __global__ void __launch_bounds__(256) corr_mfma_kernel(const CorrArgs p) {
           if (x < p.W && delta >= 0 && delta <= 2 * p.gr * p.s2 && (delta % p.s2) == 0) {
             float v = acc[tb][r] / p.c_f;
             if (p.act == FN2_ACT_LEAKY) v = leaky(v);
-            out[(((size_t)n * p.H + y) * p.W + x) * p.out_cs + p.out_c0 + pi * p.gw + delta / p.s2] =
-                from_f32<OutT>(v);
+            store_elem<OutT>(out + (((size_t)n * p.H + y) * p.W + x) * p.out_cs + p.out_c0 + pi * p.gw + delta / p.s2, v);
           }
         }
       }
@@ -257,6 +311,9 @@ int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_te
   if (!corr_fast_ok(a->c, esz, 1, md, 1, s2, md))
     return fail(FN2_ERR_UNSUPPORTED, "correlation_fused: C=%d md=%d s2=%d not covered by the MFMA kernel", a->c, md, s2);
   FN2_REQUIRE(out->dtype == a->dtype || out->dtype == FN2_F32, "correlation_fused: bad output dtype");
+  if (a->dtype == FN2_F16X2)
+    FN2_REQUIRE(a->cs % 8 == 0 && a->c0 % 8 == 0 && b->cs % 8 == 0 && b->c0 % 8 == 0 && out->cs % 8 == 0,
+                "correlation_fused: split-fp16 views are group (8) aligned");
   CorrArgs g;
   g.a = a->data; g.b = b->data; g.out = out->data;
   g.N = a->n; g.H = a->h; g.W = a->w;
@@ -270,8 +327,13 @@ int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_te
     if (out->dtype == FN2_BF16) return launch_corr<bf16_t, bf16_t>(g, a->c, s);
     return launch_corr<bf16_t, float>(g, a->c, s);
   }
-  if (out->dtype == FN2_F16) return launch_corr<f16_t, f16_t>(g, a->c, s);
-  return launch_corr<f16_t, float>(g, a->c, s);
+  if (a->dtype == FN2_F16) {
+    if (out->dtype == FN2_F16) return launch_corr<f16_t, f16_t>(g, a->c, s);
+    return launch_corr<f16_t, float>(g, a->c, s);
+  }
+  // split fp16 features: converted to fp32 operands on the way in (fp32 MFMA), split again on the way out
+  if (out->dtype == FN2_F16X2) return launch_corr<x2_t, x2_t>(g, a->c, s);
+  return launch_corr<x2_t, float>(g, a->c, s);
 }
 
 }  // extern "C"

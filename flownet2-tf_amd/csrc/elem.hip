@@ -101,7 +101,7 @@ static int check_out16(const fn2_tensor* out, int c, const char* what) {
   FN2_REQUIRE(out->c == c, "%s: output view must have %d channels", what, c);
   FN2_REQUIRE(out->cs % 8 == 0 && out->c0 % 8 == 0 && out->c0 + 16 <= out->cs,
               "%s: output needs a 16-channel, 8-aligned slot", what);
-  FN2_REQUIRE(out->dtype == FN2_F32 || out->dtype == FN2_BF16 || out->dtype == FN2_F16, "%s: bad dtype", what);
+  FN2_REQUIRE(out->dtype >= FN2_F32 && out->dtype <= FN2_F16X2, "%s: bad dtype", what);
   return FN2_OK;
 }
 
@@ -119,6 +119,9 @@ int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(stack_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        b, flow, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  else if (out->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(stack_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, flow, (x2_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
   else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(stack_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        b, flow, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
@@ -138,6 +141,9 @@ int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(fusion_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        b, flow_sd, flow_css, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+  else if (out->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(fusion_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, flow_sd, flow_css, (x2_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
   else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(fusion_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
                        a, b, flow_sd, flow_css, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);

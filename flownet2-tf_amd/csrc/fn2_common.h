@@ -49,6 +49,44 @@ template <>
 __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE, NaN-safe
 template <>
 __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
+// scalar store of one output element (x2: hi/lo halves of its group; the pointer is element-addressed)
+template <typename T>
+__device__ __forceinline__ void store_elem(T* p, float v) { *p = from_f32<T>(v); }
+
+// Split-fp16 storage element (FN2_F16X2): 4 bytes per logical channel; a group of 8 channels is 8 fp16 hi
+// parts (16 B) followed by 8 fp16 lo parts (16 B).  sizeof == 4 so that all address arithmetic is that of fp32.
+struct x2_t { unsigned raw; };
+template <typename T> struct is_x2 { static constexpr bool value = false; };
+template <> struct is_x2<x2_t> { static constexpr bool value = true; };
+
+// 8 channels -> (hi, lo) fp16 vectors
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+  h8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] = (_Float16)v[j];
+    l[j] = (_Float16)(v[j] - (float)h[j]);
+  }
+  hi = __builtin_bit_cast(uint4, h);
+  lo = __builtin_bit_cast(uint4, l);
+}
+__device__ __forceinline__ void join8(const uint4& hi, const uint4& lo, float* v) {
+  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+  const h8 h = __builtin_bit_cast(h8, hi), l = __builtin_bit_cast(h8, lo);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)h[j] + (float)l[j];
+}
+
+template <>
+__device__ __forceinline__ void store_elem<x2_t>(x2_t* p, float v) {
+  const size_t addr = reinterpret_cast<size_t>(p);  // element-addressed: 4 bytes per logical channel
+  _Float16* g = reinterpret_cast<_Float16*>(addr & ~size_t(31));
+  const int j = (int)((addr & 31) >> 2);
+  const _Float16 h = (_Float16)v;
+  g[j] = h;
+  g[8 + j] = (_Float16)(v - (float)h);
+}
 
 // N consecutive elements converted from fp32 and written with one (N*sizeof(T))-byte store
 template <typename T, int N>
@@ -59,12 +97,35 @@ __device__ __forceinline__ void store_vec(T* p, const float* v) {
   for (int j = 0; j < N; ++j) t[j] = (T)v[j];
   *reinterpret_cast<vt*>(p) = t;
 }
+// 4 consecutive channels starting at a multiple of 4 (split fp16: two 8-byte stores, hi and lo halves)
+template <>
+__device__ __forceinline__ void store_vec<x2_t, 4>(x2_t* p, const float* v) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  h4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = (_Float16)v[j];
+    l[j] = (_Float16)(v[j] - (float)h[j]);
+  }
+  // p points at logical channel c (c % 4 == 0); the group starts at p - (c & 7) channels = 4 bytes each
+  const size_t addr = reinterpret_cast<size_t>(p);
+  _Float16* g = reinterpret_cast<_Float16*>(addr & ~size_t(31));  // group base (32-byte aligned)
+  const int j0 = (int)((addr & 31) >> 2);                         // 0 or 4
+  *reinterpret_cast<h4*>(g + j0) = h;
+  *reinterpret_cast<h4*>(g + 8 + j0) = l;
+}
 // 16 consecutive elements as 16-byte stores
 template <typename T>
 __device__ __forceinline__ void store16(T* p, const float* v) {
-  constexpr int EPC = 16 / (int)sizeof(T);
+  if constexpr (is_x2<T>::value) {  // two groups of 8: hi, lo, hi, lo
+    uint4* q = reinterpret_cast<uint4*>(p);
+    split8(v, q[0], q[1]);
+    split8(v + 8, q[2], q[3]);
+  } else {
+    constexpr int EPC = 16 / (int)sizeof(T);
 #pragma unroll
-  for (int q = 0; q < 16 / EPC; ++q) store_vec<T, EPC>(p + q * EPC, v + q * EPC);
+    for (int q = 0; q < 16 / EPC; ++q) store_vec<T, EPC>(p + q * EPC, v + q * EPC);
+  }
 }
 
 // 16-bit matrix-core products on raw 16-byte operand chunks (8 elements of T)
@@ -98,8 +159,13 @@ __device__ __forceinline__ f32x4 mfma_16x16x32<float>(const uint4&, const uint4&
 template <>
 __device__ __forceinline__ f32x16 mfma_32x32x16<float>(const uint4&, const uint4&, const f32x16& c) { return c; }
 
+template <>
+__device__ __forceinline__ f32x4 mfma_16x16x32<x2_t>(const uint4&, const uint4&, const f32x4& c) { return c; }
+template <>
+__device__ __forceinline__ f32x16 mfma_32x32x16<x2_t>(const uint4&, const uint4&, const f32x16& c) { return c; }
+
 static inline bool is_16bit(int dtype) { return dtype == FN2_BF16 || dtype == FN2_F16; }
-static inline int dtype_size(int dtype) { return dtype == FN2_F32 ? 4 : 2; }
+static inline int dtype_size(int dtype) { return (dtype == FN2_F32 || dtype == FN2_F16X2) ? 4 : 2; }
 
 
 // LeakyReLU exactly as the reference writes it (utils.py:401-405): f1*x + f2*|x|

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libflownet2_hip.so")
 
-FN2_F32, FN2_BF16, FN2_F16 = 0, 1, 2
+FN2_F32, FN2_BF16, FN2_F16, FN2_F16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY = 0, 1
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3
@@ -23,11 +23,16 @@ class Fn2Tensor(C.Structure):
                 ("w", C.c_int32), ("c", C.c_int32), ("cs", C.c_int32), ("c0", C.c_int32)]
 
 
+class Fn2ConvPlan(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("cout_tile", C.c_int32), ("kstep_elems", C.c_int32),
+                ("wgt_dtype", C.c_int32)]
+
+
 class Fn2ConvDesc(C.Structure):
     _fields_ = [("inp", Fn2Tensor), ("out", Fn2Tensor), ("wgt", C.c_void_p), ("bias", C.c_void_p),
                 ("kind", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("act", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
-                ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 _i, _p, _f = C.c_int, C.c_void_p, C.c_float
@@ -46,8 +51,7 @@ PROTOTYPES = {
     "fn2_flow_warp_grad_f32": (_i, [_p] * 5 + [_i] * 4 + [_p]),
     "fn2_downsample_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
     "fn2_resize_bilinear_f32": (_i, [_p, _p] + [_i] * 6 + [_f, _p]),
-    "fn2_conv2d_cout_tile": (_i, [_i]),
-    "fn2_conv2d_weight_layout": (_i, [_i, _i, _i]),
+    "fn2_conv2d_plan": (_i, [_i, _i, _i, C.POINTER(Fn2ConvPlan)]),
     "fn2_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(Fn2ConvDesc)]),
     "fn2_conv2d": (_i, [C.POINTER(Fn2ConvDesc), _p]),
     "fn2_upsample_flow": (_i, [_p, _p, _tp, _i, _i, _i, _p]),
@@ -123,11 +127,19 @@ def dtype_code(t):
     raise ValueError("unsupported dtype %s" % t.dtype)
 
 
-def view(buf, c=None, c0=0):
-    """fn2_tensor over channels [c0, c0+c) of a dense NHWC torch buffer."""
+def view(buf, c=None, c0=0, code=None):
+    """fn2_tensor over channels [c0, c0+c) of a dense NHWC torch buffer.  `code` overrides the dtype
+    derived from the torch dtype (split-fp16 buffers live in float32 containers)."""
     n, h, w, cs = buf.shape
     assert buf.is_contiguous()
-    return Fn2Tensor(buf.data_ptr(), dtype_code(buf), n, h, w, cs - c0 if c is None else c, cs, c0)
+    return Fn2Tensor(buf.data_ptr(), dtype_code(buf) if code is None else code, n, h, w,
+                     cs - c0 if c is None else c, cs, c0)
+
+
+def conv_plan(in_code, cin_pad, cout):
+    p = Fn2ConvPlan()
+    check(lib().fn2_conv2d_plan(in_code, cin_pad, cout, C.byref(p)))
+    return p
 
 
 def to_device_f32(x):

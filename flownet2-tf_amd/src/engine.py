@@ -18,14 +18,17 @@ the fp32 MFMA parity path; "bf16" / "f16" the 16-bit MFMA throughput paths (acti
 weights 16-bit, fp32 accumulate, flow heads / warps / resize in fp32).
 """
 import ctypes as C
+import math
 
 import torch
 
 from . import _hip, netdefs, weights as W
 
-_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
-_CODE = {"f32": _hip.FN2_F32, "bf16": _hip.FN2_BF16, "f16": _hip.FN2_F16}
-_TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16"}
+# "f16x2": split-fp16 storage (fp16 hi + fp16 lo per value, 3 fp16 MFMAs per product): fp32-grade results
+# on the fp16 matrix cores; buffers are float32 containers (4 bytes per channel).
+_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f16x2": torch.float32}
+_CODE = {"f32": _hip.FN2_F32, "bf16": _hip.FN2_BF16, "f16": _hip.FN2_F16, "f16x2": _hip.FN2_F16X2}
+_TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16", "f16x2": "fn2::x2_t"}
 
 
 def _round_up(x, m):
@@ -37,14 +40,15 @@ class Engine:
         if model not in netdefs.MODELS:
             raise ValueError("unknown model %r" % model)
         if dtype not in _DT:
-            raise ValueError("dtype must be 'f32', 'bf16' or 'f16'")
+            raise ValueError("dtype must be 'f32', 'bf16', 'f16' or 'f16x2'")
         if height % 64 or width % 64:
             raise ValueError("height and width must be multiples of 64 (pad with Net.adapt_x, net.py:373-388)")
         self.lib = _hip.lib()
         self.device = device if device is not None else _hip.require_device()
         self.model, self.N, self.H, self.W = model, int(batch), int(height), int(width)
         self.dtype_name, self.tdtype = dtype, _DT[dtype]
-        self.kstep = 16 if dtype == "f32" else 32
+        self.act_code = _CODE[dtype]
+        self.code_of = {}  # data_ptr -> fn2_dtype of a buffer
         self.weights = weights
         self.ops = []      # (name, fn, args) ; args exclude the trailing stream
         self.kernel_of = []  # per op: the device kernel (template instantiation) that does the work
@@ -59,18 +63,28 @@ class Engine:
         self._alloc_workspace()
 
     # ------------------------------------------------------------------ buffers / views
-    def _buf(self, name, n, h, w, c, dtype=None):
+    def _buf(self, name, n, h, w, c, dtype=None, stem=False):
+        """Activation buffer.  dtype=torch.float32: dense fp32 (flow heads, final flows).  stem=True: the
+        packed network input; stays fp32 in split-fp16 engines (read only by the generic stem kernel)."""
         # channel stride: multiples of 64 keep every consumer on the LDS-DMA conv kernel
         # (a tap's channel run is then whole 128-byte lines); small stems stay at multiples of 8
         cs = (_round_up(c, 64) if c > 32 else _round_up(c, 8)) if dtype is None else c
         t = torch.zeros((n, h, w, cs), dtype=self.tdtype if dtype is None else dtype, device=self.device)
         assert name not in self.bufs, name
         self.bufs[name] = t
+        code = self.act_code if dtype is None else _hip.FN2_F32
+        if stem and self.act_code == _hip.FN2_F16X2:
+            code = _hip.FN2_F32
+        self.code_of[t.data_ptr()] = code
         return t
 
-    @staticmethod
-    def _v(buf, c=None, c0=0):
-        return _hip.view(buf, c, c0)
+    def _code(self, buf):
+        # batch slices (buf[:N], buf[N:]) share the storage of a registered buffer
+        base = buf.untyped_storage().data_ptr()
+        return self.code_of.get(buf.data_ptr(), self.code_of.get(base, _hip.dtype_code(buf)))
+
+    def _v(self, buf, c=None, c0=0):
+        return _hip.view(buf, c, c0, self._code(buf))
 
     def _op(self, name, fn, *args, kernel=None):
         self.kernel_of.append(kernel if kernel is not None else fn.__name__.replace("fn2_", ""))
@@ -83,21 +97,32 @@ class Engine:
         sbuf, sc0, sc = src
         dbuf, dc0, dc = dst
         assert sc == cin and dc == cout, (scope, name, sc, cin, dc, cout)
-        tile = self.lib.fn2_conv2d_cout_tile(cout)
         wname = f"{scope}/{name}/weights"
-        dt_code = _CODE[self.dtype_name]
+        in_code = self._code(sbuf)
+        esz = 2 if in_code in (_hip.FN2_BF16, _hip.FN2_F16) else 4
+        # channels per tap: whole 128-byte lines when the buffer has room (LDS-DMA kernel), else 8-aligned
         cin_pad = _round_up(cin, 8)
-        cin64 = _round_up(cin, 64)
-        if cin > 32 and sc0 + cin64 <= sbuf.shape[3] and self.lib.fn2_conv2d_weight_layout(dt_code, cin64, cout) == 1:
-            cin_pad = cin64
-        layout = self.lib.fn2_conv2d_weight_layout(dt_code, cin_pad, cout)
+        cin_line = _round_up(cin, 128 // esz)
+        if sc0 + cin_line <= sbuf.shape[3] and _hip.conv_plan(in_code, cin_line, cout).layout == 1:
+            cin_pad = cin_line
+        plan = _hip.conv_plan(in_code, cin_pad, cout)
+        tile, layout = plan.cout_tile, plan.layout
         if kind == "conv":
-            packed, cin_pad, cout_pad, kpad = W.pack_conv(self.weights[wname], tile, self.kstep, cin_pad, layout)
+            packed, cin_pad, cout_pad, kpad = W.pack_conv(self.weights[wname], tile, plan.kstep_elems, cin_pad, layout)
             bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
         else:
-            packed, cin_pad, cout_pad, kpad = W.pack_deconv(self.weights[wname], tile, self.kstep, cin_pad, layout)
+            packed, cin_pad, cout_pad, kpad = W.pack_deconv(self.weights[wname], tile, plan.kstep_elems, cin_pad, layout)
             bias = None
-        wdev = W.to_device(packed, self.tdtype, self.device)
+        out_scale = 1.0
+        if plan.wgt_dtype == _hip.FN2_F16X2:
+            # split fp16: scale the weights by 2^k so that max|w| ~ 1024 (lo parts stay normal fp16 numbers
+            # over 4 decades of weight magnitude); the kernel multiplies the accumulator by 2^-k (exact)
+            wmax = float(abs(packed).max())
+            if wmax > 0:
+                k2 = int(math.floor(math.log2(1024.0 / wmax)))
+                packed = packed * (2.0 ** k2)
+                out_scale = 2.0 ** (-k2)
+        wdev = W.packed_to_device(packed, plan.wgt_dtype, self.device)
         d = _hip.Fn2ConvDesc()
         d.inp = self._v(sbuf, sc, sc0)
         d.out = self._v(dbuf, dc, dc0)
@@ -109,16 +134,18 @@ class Engine:
         d.act = _hip.ACT_LEAKY if act else _hip.ACT_NONE
         d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
         d.wgt_layout = layout
+        d.out_scale = out_scale
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
-        tn = _TNAME[self.dtype_name]
+        tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         if kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1:
             kern = f"flow_head_kernel<{tn}>"
         elif layout == 1:
-            kern = f"conv_igemm2_kernel<{tn}, {tn}, {'2, 2' if tile == 128 else '1, 4'}>"
+            on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
+            kern = f"conv_igemm2_kernel<{tn}, {on}, {'2, 2' if tile == 128 else '1, 4'}>"
         else:
             shape = {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4", 16: "1, 1, 4"}[tile]
-            on = "float" if dbuf.dtype == torch.float32 else tn
+            on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
             kern = f"conv_igemm_kernel<{tn}, {on}, {shape}>"
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d), kernel=kern)
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
@@ -219,7 +246,7 @@ class Engine:
         N, H, W_ = self.N, self.H, self.W
         L = {s[0]: s for s in netdefs.flownet_c_layers()}
         cats = self._alloc_cats(tag, N)
-        x2 = self._buf(f"{tag}/images", 2 * N, H, W_, 3)
+        x2 = self._buf(f"{tag}/images", 2 * N, H, W_, 3, stem=True)
         v = self._v(x2, 3, 0)
         self.keep.append(v)
         self._op(f"{tag}/pack_a", self.lib.fn2_pack_image, _hip.ptr(self.in_a), N, C.byref(v), 0)
@@ -238,7 +265,7 @@ class Engine:
         self.keep += [va, vb, vo]
         tn = _TNAME[self.dtype_name]
         self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
-                 _hip.ACT_LEAKY, kernel=f"corr_mfma_kernel<{tn}, {tn}, {16 if self.dtype_name == 'f32' else 8}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
+                 _hip.ACT_LEAKY, kernel=f"corr_mfma_kernel<{tn}, {tn}, {8 if self.dtype_name in ('bf16', 'f16') else 16}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
         self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
         self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
         self._conv(scope, L["conv3_1"], (net, 0, 473), (cats[3], 0, 256))
@@ -270,14 +297,14 @@ class Engine:
         return preds
 
     def _pair_input(self, tag):
-        x = self._buf(f"{tag}/pair", self.N, self.H, self.W, 6)
+        x = self._buf(f"{tag}/pair", self.N, self.H, self.W, 6, stem=True)
         v = self._v(x, 6, 0)
         self.keep.append(v)
         self._op(f"{tag}/pack_pair", self.lib.fn2_pack_pair, _hip.ptr(self.in_a), _hip.ptr(self.in_b), C.byref(v))
         return x
 
     def _stacked_input(self, tag, flow):
-        x = self._buf(f"{tag}/stack", self.N, self.H, self.W, 16)
+        x = self._buf(f"{tag}/stack", self.N, self.H, self.W, 16, stem=True)
         v = self._v(x, 12, 0)
         self.keep.append(v)
         self._op(f"{tag}/stack_input", self.lib.fn2_stack_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
@@ -298,7 +325,7 @@ class Engine:
         css = self._net_css(scope + "/FlowNetCSS", tag + "/CSS")
         sd = self._net_sd(scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD"))
         L = {s[0]: s for s in netdefs.fusion_layers()}
-        xf = self._buf(f"{tag}/fusion_in", N, H, W_, 16)
+        xf = self._buf(f"{tag}/fusion_in", N, H, W_, 16, stem=True)
         v = self._v(xf, 11, 0)
         self.keep.append(v)
         self._op(f"{tag}/fusion_input", self.lib.fn2_fusion_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),

@@ -27,7 +27,7 @@ if __name__ == '__main__':
     parser.add_argument('--out', type=str, required=True, help='Path to output flow result')
     parser.add_argument('--checkpoint', type=str, default='./checkpoints/FlowNetCS/flownet-CS.ckpt-0',
                         help='.npz weights keyed by the reference variable names')
-    parser.add_argument('--dtype', type=str, default='f32', choices=['f32', 'bf16', 'f16'])
+    parser.add_argument('--dtype', type=str, default='f32', choices=['f32', 'bf16', 'f16', 'f16x2'])
     FLAGS = parser.parse_args()
 
     # Verify arguments are valid

@@ -105,3 +105,31 @@ def pack_deconv(w_hwoi, cout_tile, kstep_elems, cin_pad=None, layout=0):
 
 def to_device(arr, dtype, device):
     return torch.from_numpy(np.ascontiguousarray(arr)).to(device=device, dtype=dtype).contiguous()
+
+
+def split_f16x2(packed):
+    """fp32 [..., k] (k % 8 == 0) -> split-fp16 storage: per group of 8 values, 8 fp16 hi parts then 8
+    fp16 lo parts (x = hi + lo); returned as float16 [..., 2k] (4 bytes per logical element)."""
+    p = np.ascontiguousarray(packed, np.float32)
+    assert p.shape[-1] % 8 == 0
+    g = p.reshape(p.shape[:-1] + (p.shape[-1] // 8, 8))
+    hi = g.astype(np.float16)
+    lo = (g - hi.astype(np.float32)).astype(np.float16)
+    return np.stack([hi, lo], axis=-2).reshape(p.shape[:-1] + (2 * p.shape[-1],))
+
+
+def join_f16x2(split):
+    """Inverse of split_f16x2 (float16 [..., 2k] -> float32 [..., k])."""
+    s = np.asarray(split, np.float16)
+    g = s.reshape(s.shape[:-1] + (s.shape[-1] // 16, 2, 8)).astype(np.float32)
+    return (g[..., 0, :] + g[..., 1, :]).reshape(s.shape[:-1] + (s.shape[-1] // 2,))
+
+
+_TORCH_OF_CODE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+
+
+def packed_to_device(packed, wgt_code, device):
+    """Packed fp32 weight -> device tensor of the element type the kernel plan asks for."""
+    if wgt_code == 3:
+        return torch.from_numpy(split_f16x2(packed)).to(device).contiguous()
+    return to_device(packed, _TORCH_OF_CODE[wgt_code], device)

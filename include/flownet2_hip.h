@@ -57,7 +57,12 @@ typedef enum {
   FN2_ERR_HIP = -3               /* a HIP runtime call or kernel launch failed */
 } fn2_status;
 
-typedef enum { FN2_F32 = 0, FN2_BF16 = 1, FN2_F16 = 2 } fn2_dtype;
+/* FN2_F16X2: "split fp16" storage of fp32-grade values: every group of 8 consecutive channels is 16 bytes
+ * of fp16 hi parts followed by 16 bytes of fp16 lo parts (x = hi + lo, 22 significant bits, 4 bytes per
+ * channel like fp32).  Products are formed on the fp16 matrix cores as hi*hi + hi*lo + lo*hi with fp32
+ * accumulation: fp32-grade results at 3/16 of the fp32-MFMA cost.  Channel offsets/strides of such views
+ * must be multiples of 8. */
+typedef enum { FN2_F32 = 0, FN2_BF16 = 1, FN2_F16 = 2, FN2_F16X2 = 3 } fn2_dtype;
 
 typedef enum { FN2_ACT_NONE = 0, FN2_ACT_LEAKY = 1 /* 0.55x + 0.45|x|, utils.py:401-405 */ } fn2_act;
 
@@ -119,8 +124,7 @@ int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in
  *           four 2x2 stride-1 phase convolutions; no bias in the reference.
  * `wgt` is the layer's weight pre-packed by fn2_pack_* layout rules (see DESIGN.md "weights"):
  *   [phase][cout_pad][kpad] elements of in.dtype, k = (tap, channel) with channels padded to a
- *   multiple of 8, kpad a multiple of 32 (bf16) / 16 (f32) elements; cout_pad a multiple of the
- *   block's cout tile (fn2_conv2d_cout_tile). */
+ *   multiple of 8, kpad a multiple of the k-step; cout_pad a multiple of the block's cout tile (fn2_conv2d_plan). */
 typedef struct {
   fn2_tensor in;       /* in.c = logical Cin; in.cs and in.c0 multiples of 8 */
   fn2_tensor out;      /* out.c = Cout; out.dtype may be FN2_F32 while in is bf16 (flow heads) */
@@ -132,18 +136,26 @@ typedef struct {
   int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */
   int32_t cout_pad;    /* rows per phase in the packed weight */
   int32_t kpad;        /* elements per packed row */
-  int32_t wgt_layout;  /* row order of the packed weight: value of fn2_conv2d_weight_layout() */
+  int32_t wgt_layout;  /* row order of the packed weight: fn2_conv_plan.layout */
+  float out_scale;     /* accumulator scale applied before the bias (0 = 1): lets the packer store
+                          2^k-scaled weights so that split-fp16 lo parts stay normal fp16 numbers */
   void* workspace;     /* fp32 scratch for split-K partial sums, or NULL (then no split-K) */
   int64_t workspace_bytes;
 } fn2_conv_desc;
 
-/* Cout tile the kernel will use for this Cout (16, 32, 64 or 128): cout_pad must be a multiple. */
-int fn2_conv2d_cout_tile(int cout);
-/* Row order the kernel chosen for (dtype, cin_pad, cout) expects in the packed weight:
- *   0: row r = output channel r;
- *   1: LDS-DMA fast path: inside every group of 64 rows, row t*16+g*4+r = output channel g*16+t*4+r
- *      (t,g,r in 0..3), so that a lane's 16 accumulators are 16 consecutive channels. */
-int fn2_conv2d_weight_layout(int in_dtype, int cin_pad, int cout);
+/* How fn2_conv2d runs a layer of this (input dtype, padded Cin, Cout), i.e. how its weight must be packed:
+ *   cout_tile   rows per block: cout_pad must be a multiple;
+ *   kstep_elems kpad must be a multiple (elements);
+ *   wgt_dtype   element type of the packed weight (FN2_F16X2 activations: split pairs on the LDS-DMA
+ *               kernel, plain fp32 on the generic kernel and the flow heads);
+ *   layout      0: row r = output channel r;
+ *               1: LDS-DMA kernel: inside every group of 32 rows, row (r&3)+8(r>>2)+4h = output channel
+ *                  16h+r (h in 0..1, r in 0..15), so that a lane's 16 accumulators are 16 consecutive
+ *                  channels. */
+typedef struct {
+  int32_t layout, cout_tile, kstep_elems, wgt_dtype;
+} fn2_conv_plan;
+int fn2_conv2d_plan(int in_dtype, int cin_pad, int cout, fn2_conv_plan* plan);
 /* Bytes of workspace with which this layer would use its preferred split-K factor (0 = none needed).
  * The caller owns the workspace (the reference: ctx->allocate_temp, correlation_kernel.cc:66-80);
  * one buffer of the maximum over layers can be shared by all launches on a stream. */

@@ -15,42 +15,65 @@ def rnd(shape, seed, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
 
 
+_TD = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f16x2": torch.float32}
+_CODE = {"f32": 0, "bf16": 1, "f16": 2, "f16x2": 3}
+
+
+def _to_dev(x, dtype):
+    """fp32 NHWC numpy -> device tensor in the engine's storage format."""
+    from src import weights as W
+    if dtype == "f16x2":
+        return torch.from_numpy(W.split_f16x2(x).view(np.float32)).cuda()
+    return torch.from_numpy(x).cuda().to(_TD[dtype])
+
+
+def _from_dev(t, code):
+    from src import weights as W
+    if code == 3:
+        return W.join_f16x2(t.cpu().numpy().view(np.float16))
+    return t.float().cpu().numpy()
+
+
 def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0, cout_off=0, extra_out=0,
-             use_ws=True, force_generic=False):
-    """Drive the C ABI directly.  x: [N,H,W,Cin] fp32.  Returns fp32 numpy [N,oh,ow,Cout]."""
+             use_ws=True, force_generic=False, in_f32=False):
+    """Drive the C ABI directly.  x: [N,H,W,Cin] fp32.  Returns fp32 numpy [N,oh,ow,Cout].
+    in_f32: fp32 input into a non-fp32 engine format (the stem of a split-fp16 network)."""
     from src import _hip, weights as W
     lib = _hip.lib()
-    td = torch.float32 if dtype == "f32" else torch.bfloat16
     N, H, Wd, cin = x.shape
     cout = w.shape[3] if kind == "conv" else w.shape[2]
+    in_code = 0 if in_f32 else _CODE[dtype]
     cs_in = (cin_off + cin + 63) // 64 * 64 if cin > 32 else (cin_off + cin + 7) // 8 * 8
-    xin = torch.zeros((N, H, Wd, cs_in), dtype=td, device="cuda")
-    xin[..., cin_off:cin_off + cin] = torch.from_numpy(x).cuda().to(td)
+    xpad = np.zeros((N, H, Wd, cs_in), np.float32)
+    xpad[..., cin_off:cin_off + cin] = x
+    xin = _to_dev(xpad, "f32" if in_f32 else dtype)
     if kind == "conv":
         oh, ow = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
     else:
         oh, ow = 2 * H, 2 * Wd
-    od = torch.float32 if (out_f32 or dtype == "f32") else torch.bfloat16
+    out_code = 0 if (out_f32 or dtype == "f32") else _CODE[dtype]
     cs_out = cout_off + cout + extra_out
-    out = torch.full((N, oh, ow, cs_out), 7.0, dtype=od, device="cuda")
-    tile = lib.fn2_conv2d_cout_tile(cout)
-    kstep = 32 if dtype == "bf16" else 16
-    code = 1 if dtype == "bf16" else 0
+    if out_code == 3:
+        cs_out = (cs_out + 7) // 8 * 8
+    out = _to_dev(np.full((N, oh, ow, cs_out), 7.0, np.float32), "f32" if out_code == 0 else dtype)
+    esz = 2 if in_code in (1, 2) else 4
     cin_pad = (cin + 7) // 8 * 8
-    cin64 = (cin + 63) // 64 * 64
-    if not force_generic and cin > 32 and lib.fn2_conv2d_weight_layout(code, cin64, cout) == 1:
-        cin_pad = cin64
-    layout = 0 if force_generic else lib.fn2_conv2d_weight_layout(code, cin_pad, cout)
-    run_conv.last_layout = layout
-    if kind == "conv":
-        packed, cin_pad, cout_pad, kpad = W.pack_conv(w, tile, kstep, cin_pad, layout)
-    else:
-        packed, cin_pad, cout_pad, kpad = W.pack_deconv(w, tile, kstep, cin_pad, layout)
-    wdev = torch.from_numpy(packed).cuda().to(td).contiguous()
+    cin_line = (cin + 128 // esz - 1) // (128 // esz) * (128 // esz)
+    if not force_generic and cin_off + cin_line <= cs_in and _hip.conv_plan(in_code, cin_line, cout).layout == 1:
+        cin_pad = cin_line
+    plan = _hip.conv_plan(in_code, cin_pad, cout)
+    run_conv.last_layout = plan.layout
+    pack = W.pack_conv if kind == "conv" else W.pack_deconv
+    packed, cin_pad, cout_pad, kpad = pack(w, plan.cout_tile, plan.kstep_elems, cin_pad, plan.layout)
+    out_scale = 1.0
+    if plan.wgt_dtype == 3:
+        k2 = int(np.floor(np.log2(1024.0 / np.abs(packed).max())))
+        packed, out_scale = packed * 2.0 ** k2, 2.0 ** -k2
+    wdev = W.packed_to_device(packed, plan.wgt_dtype, "cuda")
     bdev = torch.from_numpy(b).cuda() if b is not None else None
     d = _hip.Fn2ConvDesc()
-    d.inp = _hip.view(xin, cin, cin_off)
-    d.out = _hip.view(out, cout, cout_off)
+    d.inp = _hip.view(xin, cin, cin_off, in_code)
+    d.out = _hip.view(out, cout, cout_off, out_code)
     d.wgt = wdev.data_ptr()
     d.bias = bdev.data_ptr() if bdev is not None else None
     d.kind = 0 if kind == "conv" else 1
@@ -58,7 +81,8 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
     d.stride, d.pad = stride, pad
     d.act = 1 if act else 0
     d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
-    d.wgt_layout = layout
+    d.wgt_layout = plan.layout
+    d.out_scale = out_scale
     need = int(lib.fn2_conv2d_workspace_bytes(C.byref(d)))
     ws = None
     if use_ws and need > 0:
@@ -67,12 +91,12 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
     run_conv.last_ws_bytes = need if use_ws else 0
     _hip.check(lib.fn2_conv2d(C.byref(d), _hip.stream_ptr()))
     torch.cuda.synchronize()
-    res = out.float().cpu().numpy()
+    res = _from_dev(out, out_code)
     # nothing outside the slice may be touched
     if cout_off:
         assert np.all(res[..., :cout_off] == 7.0)
     if extra_out:
-        assert np.all(res[..., cout_off + cout:] == 7.0)
+        assert np.all(res[..., cout_off + cout:cout_off + cout + extra_out] == 7.0)
     return res[..., cout_off:cout_off + cout]
 
 
@@ -101,19 +125,19 @@ def test_conv_f32_matches_oracle(k, s, p, cin, cout, H, W):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)  # fp32 accumulation-order tolerance
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_fast_and_generic_kernels_agree(dtype):
-    """The LDS-DMA kernel (permuted weight rows) and the generic kernel on the same layer."""
-    x = torch.from_numpy(rnd((2, 12, 16, 128), 20)).bfloat16().float().numpy()
-    w = torch.from_numpy(rnd((3, 3, 128, 192), 21, (2.0 / (9 * 128)) ** 0.5)).bfloat16().float().numpy()
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_fast_and_generic_kernels(dtype):
+    """The same 3x3 stride-2 layer on the LDS-DMA kernel (Cin 128: whole 128-byte lines, permuted weight rows)
+    and, with Cin 72, on the generic kernel."""
     b = rnd((192,), 22, 0.1)
-    want = refnn.conv2d(x, w, b, stride=2, padding=1, activation=refnn.leaky_relu)
-    fast = run_conv(x, w, b, "conv", 3, 2, 1, True, dtype, out_f32=True, cout_off=8, use_ws=False)
-    assert run_conv.last_layout == 1
-    gen = run_conv(x, w, b, "conv", 3, 2, 1, True, dtype, out_f32=True, cout_off=8, use_ws=False, force_generic=True)
-    assert run_conv.last_layout == 0
-    np.testing.assert_allclose(fast, want, rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(gen, want, rtol=2e-5, atol=2e-5)
+    for cin, layout in ((128, 1), (72, 0)):
+        x = torch.from_numpy(rnd((2, 12, 16, cin), 20)).bfloat16().float().numpy()
+        w = torch.from_numpy(rnd((3, 3, cin, 192), 21, (2.0 / (9 * cin)) ** 0.5)).bfloat16().float().numpy()
+        want = refnn.conv2d(x, w, b, stride=2, padding=1, activation=refnn.leaky_relu)
+        got = run_conv(x, w, b, "conv", 3, 2, 1, True, dtype, out_f32=True, cout_off=8, use_ws=False,
+                       force_generic=(layout == 0))
+        assert run_conv.last_layout == layout
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
 def test_conv_f32_linear_no_bias_and_slices():
@@ -167,6 +191,46 @@ def test_splitk_equals_single_pass(dtype):
     gotd = run_conv(xd, wd, None, "deconv", 4, 2, 1, True, "f32")
     assert run_conv.last_ws_bytes > 0
     np.testing.assert_allclose(gotd, wantd, rtol=2e-5, atol=2e-5)
+
+
+X2_CASES = [(5, 2, 2, 64, 128, 24, 32), (3, 1, 1, 256, 256, 6, 8), (3, 2, 1, 128, 512, 12, 16),
+            (3, 1, 1, 473, 256, 6, 8), (1, 1, 0, 256, 32, 6, 8), (3, 1, 1, 82, 16, 16, 16), (3, 1, 1, 162, 32, 8, 8)]
+
+
+@pytest.mark.parametrize("k,s,p,cin,cout,H,W", X2_CASES)
+def test_conv_split_fp16_matches_oracle(k, s, p, cin, cout, H, W):
+    """split-fp16 storage + 3 fp16 MFMAs per product: fp32-grade (22-bit operands, fp32 accumulate)."""
+    x = rnd((2, H, W, cin), 0)
+    w = rnd((k, k, cin, cout), 1, (2.0 / (k * k * cin)) ** 0.5)
+    b = rnd((cout,), 2, 0.1)
+    want = refnn.conv2d(x, w, b, stride=s, padding=p, activation=refnn.leaky_relu)
+    got = run_conv(x, w, b, "conv", k, s, p, True, "f16x2", cout_off=8, extra_out=8)
+    assert run_conv.last_layout == 1
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_split_fp16_stem_deconv_head():
+    # fp32 stem input -> split-fp16 output on the generic kernel (conv1 of a split-fp16 network)
+    x = rnd((2, 32, 48, 6), 3)
+    w = rnd((7, 7, 6, 64), 4, (2.0 / (49 * 6)) ** 0.5)
+    b = rnd((64,), 5, 0.1)
+    want = refnn.conv2d(x, w, b, stride=2, padding=3, activation=refnn.leaky_relu)
+    got = run_conv(x, w, b, "conv", 7, 2, 3, True, "f16x2", in_f32=True)
+    assert run_conv.last_layout == 0
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+    # transposed conv (4 phases) with split-K
+    xd = rnd((1, 3, 4, 512), 12)
+    wd = rnd((4, 4, 256, 512), 13, (2.0 / (4 * 512)) ** 0.5)
+    wantd = refnn.conv2d_transpose(xd, wd, activation=refnn.leaky_relu)
+    gotd = run_conv(xd, wd, None, "deconv", 4, 2, 1, True, "f16x2", cout_off=8)
+    np.testing.assert_allclose(gotd, wantd, rtol=2e-5, atol=2e-5)
+    # flow head reading split-fp16 activations
+    xh = rnd((2, 12, 16, 194), 14)
+    wh = rnd((3, 3, 194, 2), 15, 0.05)
+    bh = rnd((2,), 16, 0.1)
+    wanth = refnn.conv2d(xh, wh, bh, stride=1, padding=1)
+    goth = run_conv(xh, wh, bh, "conv", 3, 1, 1, False, "f16x2", out_f32=True)
+    np.testing.assert_allclose(goth, wanth, rtol=2e-5, atol=2e-5)
 
 
 def test_upsample_flow_matches_oracle():

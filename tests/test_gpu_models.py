@@ -98,6 +98,24 @@ def test_bf16_path_bounded(model):
     assert e < 0.05 * mag
 
 
+@pytest.mark.parametrize("model", ["FlowNetS", "FlowNetC", "FlowNetSD", "FlowNet2"])
+def test_split_fp16_path_meets_parity_bar(model):
+    """f16x2: split-fp16 storage, 3 fp16 MFMAs per product, fp32 accumulate.  Same 1e-3 px bar as fp32."""
+    n, h, w = (1, 64, 64) if model == "FlowNet2" else (2, 64, 128)
+    out, want = run(model, "f16x2", n, h, w)
+    e = epe(out["flow"], want["flow"])
+    mag = float(np.sqrt((want["flow"] ** 2).sum(-1)).mean())
+    print(model, "f16x2 mean EPE vs oracle %.3e px (mean |flow| %.2f px)" % (e, mag))
+    assert e < EPE_TOL
+
+
+def test_split_fp16_full_size_flownet_c():
+    out, want = run("FlowNetC", "f16x2", 1, 384, 512)
+    e = epe(out["flow"], want["flow"])
+    print("FlowNetC 512x384 f16x2 mean EPE vs oracle %.3e px" % e)
+    assert e < EPE_TOL
+
+
 @pytest.mark.parametrize("model", ["FlowNetS", "FlowNetC", "FlowNet2"])
 def test_f16_path_reported(model):
     """fp16 activations/weights (11 mantissa bits), fp32 accumulate: measured against the oracle and

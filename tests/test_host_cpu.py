@@ -50,14 +50,36 @@ def test_correlation_out_shape_and_validation_without_gpu(hip):
     assert rc == hip.ERR_INVALID_ARGUMENT and b"fit" in lib.fn2_last_error()
 
 
-def test_cout_tile_and_weight_layout_rules(hip):
-    lib = hip.lib()
-    assert [lib.fn2_conv2d_cout_tile(c) for c in (2, 16, 17, 32, 33, 64, 65, 1024)] == [16, 16, 32, 32, 64, 64, 128, 128]
-    assert lib.fn2_conv2d_weight_layout(hip.FN2_BF16, 64, 128) == 1
-    assert lib.fn2_conv2d_weight_layout(hip.FN2_BF16, 32, 128) == 0   # 64 bytes per tap: generic kernel
-    assert lib.fn2_conv2d_weight_layout(hip.FN2_F32, 32, 128) == 1
-    assert lib.fn2_conv2d_weight_layout(hip.FN2_BF16, 256, 2) == 0    # flow head
-    assert lib.fn2_conv2d_weight_layout(hip.FN2_BF16, 256, 32) == 0
+def test_conv_plan_rules(hip):
+    def plan(code, cin_pad, cout):
+        p = hip.conv_plan(code, cin_pad, cout)
+        return (p.layout, p.cout_tile, p.kstep_elems, p.wgt_dtype)
+    assert plan(hip.FN2_BF16, 64, 128) == (1, 128, 64, hip.FN2_BF16)   # whole 128-byte lines: LDS-DMA kernel
+    assert plan(hip.FN2_BF16, 32, 128) == (0, 128, 32, hip.FN2_BF16)   # 64 bytes per tap: generic kernel
+    assert plan(hip.FN2_F32, 32, 64) == (1, 64, 32, hip.FN2_F32)
+    assert plan(hip.FN2_F32, 8, 64) == (0, 64, 16, hip.FN2_F32)        # stem
+    assert plan(hip.FN2_F16, 256, 32) == (1, 64, 64, hip.FN2_F16)      # small Cout rides the 64-row tile
+    assert plan(hip.FN2_BF16, 256, 2) == (0, 16, 32, hip.FN2_BF16)     # flow head
+    assert plan(hip.FN2_F16X2, 256, 2) == (0, 16, 16, hip.FN2_F32)     # flow head on split fp16: fp32 weights
+    assert plan(hip.FN2_F16X2, 96, 16) == (1, 64, 32, hip.FN2_F16X2)
+    with pytest.raises(NotImplementedError):
+        hip.conv_plan(hip.FN2_F16X2, 8, 64)                            # split fp16 has no generic input path
+    with pytest.raises(ValueError):
+        hip.conv_plan(hip.FN2_F32, 12, 64)
+
+
+def test_split_fp16_roundtrip():
+    from src import weights as W
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((5, 7, 24)) * np.exp(rng.uniform(-6, 3, (5, 7, 24)))).astype(np.float32)
+    s = W.split_f16x2(x)
+    assert s.dtype == np.float16 and s.shape == (5, 7, 48)
+    np.testing.assert_array_equal(s[..., :8].astype(np.float32), x[..., :8].astype(np.float16).astype(np.float32))
+    back = W.join_f16x2(s)
+    err = np.abs(back - x)
+    big = np.abs(x) >= 0.125   # lo part is a normal fp16 number: 22 significant bits
+    assert np.max(err[big] / np.abs(x)[big]) < 2.0 ** -21
+    assert np.max(err[~big]) <= 2.0 ** -24  # lo part subnormal: absolute error half an fp16 subnormal step
 
 
 def test_pack_conv_layouts():

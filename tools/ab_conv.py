@@ -43,11 +43,14 @@ def build(name, dtype):
     else:
         w = rng.standard_normal((4, 4, cout, cin)).astype(np.float32) * 0.05
         oh, ow = 2 * H, 2 * Wd
-    tile = lib.fn2_conv2d_cout_tile(cout)
-    cin_pad = cs_in if lib.fn2_conv2d_weight_layout(code, cs_in, cout) == 1 else (cin + 7) // 8 * 8
-    layout = lib.fn2_conv2d_weight_layout(code, cin_pad, cout)
+    esz = 4 if dtype == "f32" else 2
+    line = 128 // esz
+    cin_line = (cin + line - 1) // line * line
+    cin_pad = cin_line if _hip.conv_plan(code, cin_line, cout).layout == 1 else (cin + 7) // 8 * 8
+    plan = _hip.conv_plan(code, cin_pad, cout)
     pack = W.pack_conv if kind == "conv" else W.pack_deconv
-    packed, cin_pad, cout_pad, kpad = pack(w, tile, 16 if dtype == "f32" else 32, cin_pad, layout)
+    packed, cin_pad, cout_pad, kpad = pack(w, plan.cout_tile, plan.kstep_elems, cin_pad, plan.layout)
+    layout = plan.layout
     wdev = torch.from_numpy(packed).cuda().to(td).contiguous()
     out = torch.zeros((N, oh, ow, (cout + 63) // 64 * 64), dtype=td, device="cuda")
     d = _hip.Fn2ConvDesc()
