@@ -449,13 +449,16 @@ __global__ void __launch_bounds__(256) upsample_flow_kernel(const float* __restr
   }
 }
 
-// images fp32 [n,h,w,3] -> view channels [c_dst, c_dst+3)
+// images fp32 [n,h,w,3] -> channels [c_dst, c_dst+3) of the interior of a view padded by `pad` pixels
 template <typename OutT>
 __global__ void __launch_bounds__(256) pack_image_kernel(const float* __restrict__ img, OutT* __restrict__ out,
-                                                         long npix, long pix0, int out_cs, int c_dst) {
+                                                         int n, int h, int w, int n0, int pad, int out_cs, int c_dst) {
+  const long npix = (long)n * h * w;
+  const int hp = h + 2 * pad, wp = w + 2 * pad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), nn = (int)(i / w / h);
     const float* s = img + i * 3;
-    OutT* d = out + (size_t)(pix0 + i) * out_cs + c_dst;
+    OutT* d = out + (((size_t)(n0 + nn) * hp + y + pad) * wp + x + pad) * out_cs + c_dst;
     store_elem<OutT>(d, s[0]);
     store_elem<OutT>(d + 1, s[1]);
     store_elem<OutT>(d + 2, s[2]);
@@ -523,11 +526,12 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   rc = check_view(&d->out, "conv2d output");
   if (rc) return rc;
   FN2_REQUIRE(d->wgt, "conv2d: null weights");
-  FN2_REQUIRE(d->kind == 0 || d->kind == 1, "conv2d: kind must be 0 (conv) or 1 (deconv)");
+  FN2_REQUIRE(d->kind >= 0 && d->kind <= 2, "conv2d: kind must be 0 (conv), 1 (deconv) or 2 (stem row-run conv)");
   FN2_REQUIRE(d->in.n == d->out.n, "conv2d: batch mismatch");
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cin_pad >= d->in.c, "conv2d: cin_pad must be a multiple of 8 >= Cin");
   FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: input channel stride/offset must be multiples of 8");
-  FN2_REQUIRE(d->in.c0 + d->cin_pad <= d->in.cs, "conv2d: padded input channels exceed the buffer stride");
+  if (d->kind != 2)
+    FN2_REQUIRE(d->in.c0 + d->cin_pad <= d->in.cs, "conv2d: padded input channels exceed the buffer stride");
   const int esz = dtype_size(d->in.dtype);
   const int CH = 16 / esz;
   FN2_REQUIRE(d->kpad > 0 && d->kpad % (4 * CH) == 0, "conv2d: kpad must be a multiple of one k-step");
@@ -557,6 +561,20 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     a.OW = (d->in.w + 2 * d->pad - d->kw) / d->stride + 1;
     FN2_REQUIRE(a.OH >= 1 && a.OW >= 1, "conv2d: kernel does not fit");
     FN2_REQUIRE(d->out.h == a.OH && d->out.w == a.OW, "conv2d: output spatial size %dx%d != expected %dx%d",
+                d->out.h, d->out.w, a.OH, a.OW);
+    a.deconv = 0;
+  } else if (d->kind == 2) {
+    // stem row-run conv: the kw taps x cs channels of a kernel row are one contiguous run of the
+    // pre-padded NHWC input; runs past the row end read the next row / out-of-range zeros under zero weights
+    FN2_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->pad == 0, "stem conv: pad must be baked into the input buffer");
+    FN2_REQUIRE(d->in.c0 == 0 && d->in.c == d->in.cs, "stem conv: the input view must be the whole buffer");
+    FN2_REQUIRE(d->cin_pad >= d->kw * d->in.cs, "stem conv: run (cin_pad) shorter than kw*cs");
+    FN2_REQUIRE(d->wgt_layout == 1, "stem conv: runs on the LDS-DMA kernel only (run must be whole 128-byte lines)");
+    a.KH = d->kh; a.KW = 1; a.stride = d->stride; a.pad = 0;
+    a.OH = (d->in.h - d->kh) / d->stride + 1;
+    a.OW = (d->in.w - d->kw) / d->stride + 1;
+    FN2_REQUIRE(a.OH >= 1 && a.OW >= 1, "stem conv: kernel does not fit");
+    FN2_REQUIRE(d->out.h == a.OH && d->out.w == a.OW, "stem conv: output spatial size %dx%d != expected %dx%d",
                 d->out.h, d->out.w, a.OH, a.OW);
     a.deconv = 0;
   } else {
@@ -710,41 +728,42 @@ int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, in
   return FN2_OK;
 }
 
-static int pack_one(const float* img, const fn2_tensor* out, int n, int n0, int c_dst, void* stream) {
-  const long npix = (long)n * out->h * out->w, pix0 = (long)n0 * out->h * out->w;
+static int pack_one(const float* img, const fn2_tensor* out, int n, int n0, int c_dst, int pad, void* stream) {
+  FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "pack: bad border");
+  const int h = out->h - 2 * pad, w = out->w - 2 * pad;
+  const long npix = (long)n * h * w;
+  const dim3 g(grid_for(npix, 256)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  const int cd = out->c0 + c_dst;
   if (out->dtype == FN2_F32)
-    hipLaunchKernelGGL(pack_image_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img,
-                       (float*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+    hipLaunchKernelGGL(pack_image_kernel<float>, g, b, 0, s, img, (float*)out->data, n, h, w, n0, pad, out->cs, cd);
   else if (out->dtype == FN2_F16X2)
-    hipLaunchKernelGGL(pack_image_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       img, (x2_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+    hipLaunchKernelGGL(pack_image_kernel<x2_t>, g, b, 0, s, img, (x2_t*)out->data, n, h, w, n0, pad, out->cs, cd);
   else if (out->dtype == FN2_BF16)
-    hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       img, (bf16_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+    hipLaunchKernelGGL(pack_image_kernel<bf16_t>, g, b, 0, s, img, (bf16_t*)out->data, n, h, w, n0, pad, out->cs, cd);
   else
-    hipLaunchKernelGGL(pack_image_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       img, (f16_t*)out->data, npix, pix0, out->cs, out->c0 + c_dst);
+    hipLaunchKernelGGL(pack_image_kernel<f16_t>, g, b, 0, s, img, (f16_t*)out->data, n, h, w, n0, pad, out->cs, cd);
   FN2_CHECK_LAUNCH("pack_image");
   return FN2_OK;
 }
 
-int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, void* stream) {
+int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, int pad, void* stream) {
   FN2_REQUIRE(a && b, "pack_pair: null pointer");
   int rc = check_view(out, "pack_pair output");
   if (rc) return rc;
   FN2_REQUIRE(out->c == 6, "pack_pair: output view must have 6 channels");
-  rc = pack_one(a, out, out->n, 0, 0, stream);
+  rc = pack_one(a, out, out->n, 0, 0, pad, stream);
   if (rc) return rc;
-  return pack_one(b, out, out->n, 0, 3, stream);
+  return pack_one(b, out, out->n, 0, 3, pad, stream);
 }
 
-int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, void* stream) {
+int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, int pad, void* stream) {
   FN2_REQUIRE(img, "pack_image: null pointer");
   int rc = check_view(out, "pack_image output");
   if (rc) return rc;
   FN2_REQUIRE(out->c == 3, "pack_image: output view must have 3 channels");
   FN2_REQUIRE(n_img >= 1 && n0 >= 0 && n0 + n_img <= out->n, "pack_image: rows [n0, n0+n_img) outside the buffer");
-  return pack_one(img, out, n_img, n0, 0, stream);
+  return pack_one(img, out, n_img, n0, 0, pad, stream);
 }
 
 }  // extern "C"

@@ -28,7 +28,7 @@ __device__ __forceinline__ void warp3(const float* __restrict__ img, long nb, in
 template <typename OutT>
 __global__ void __launch_bounds__(256) stack_input_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           const float* __restrict__ flow, OutT* __restrict__ out,
-                                                          int N, int H, int W, int out_cs, int out_c0) {
+                                                          int N, int H, int W, int out_cs, int out_c0, int pad) {
   const long npix = (long)N * H * W;
   for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
     const int x = (int)(pix % W), y = (int)((pix / W) % H);
@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) stack_input_kernel(const float* __restric
     v[10] = f.y * 0.05f;
     v[11] = sqrtf(e);     // brightness error, flownet_cs.py:24-27
     v[12] = v[13] = v[14] = v[15] = 0.f;
-    store16<OutT>(out + (size_t)pix * out_cs + out_c0, v);
+    const size_t opix = ((size_t)(pix / W / H) * (H + 2 * pad) + y + pad) * (W + 2 * pad) + x + pad;
+    store16<OutT>(out + opix * out_cs + out_c0, v);
   }
 }
 
@@ -59,7 +60,7 @@ template <typename OutT>
 __global__ void __launch_bounds__(256) fusion_input_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                            const float* __restrict__ fsd,
                                                            const float* __restrict__ fcss, OutT* __restrict__ out,
-                                                           int N, int H, int W, int out_cs, int out_c0) {
+                                                           int N, int H, int W, int out_cs, int out_c0, int pad) {
   const long npix = (long)N * H * W;
   for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
     const int x = (int)(pix % W), y = (int)((pix / W) % H);
@@ -85,7 +86,8 @@ __global__ void __launch_bounds__(256) fusion_input_kernel(const float* __restri
     v[9] = sqrtf(esd);                                             // :35
     v[10] = sqrtf(ecs);                                            // :39
     v[11] = v[12] = v[13] = v[14] = v[15] = 0.f;
-    store16<OutT>(out + (size_t)pix * out_cs + out_c0, v);
+    const size_t opix = ((size_t)(pix / W / H) * (H + 2 * pad) + y + pad) * (W + 2 * pad) + x + pad;
+    store16<OutT>(out + opix * out_cs + out_c0, v);
   }
 }
 
@@ -111,45 +113,47 @@ using namespace fn2;
 
 extern "C" {
 
-int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out, void* stream) {
+int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out, int pad, void* stream) {
   FN2_REQUIRE(a && b && flow, "stack_input: null pointer");
   int rc = check_out16(out, 12, "stack_input");
   if (rc) return rc;
-  const long npix = (long)out->n * out->h * out->w;
+  FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "bad border");
+  const long npix = (long)out->n * (out->h - 2 * pad) * (out->w - 2 * pad);
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(stack_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       b, flow, (float*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else if (out->dtype == FN2_F16X2)
     hipLaunchKernelGGL(stack_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (x2_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       b, flow, (x2_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(stack_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       b, flow, (bf16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else
     hipLaunchKernelGGL(stack_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (f16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       b, flow, (f16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   FN2_CHECK_LAUNCH("stack_input");
   return FN2_OK;
 }
 
 int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const float* flow_css,
-                     const fn2_tensor* out, void* stream) {
+                     const fn2_tensor* out, int pad, void* stream) {
   FN2_REQUIRE(a && b && flow_sd && flow_css, "fusion_input: null pointer");
   int rc = check_out16(out, 11, "fusion_input");
   if (rc) return rc;
-  const long npix = (long)out->n * out->h * out->w;
+  FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "bad border");
+  const long npix = (long)out->n * (out->h - 2 * pad) * (out->w - 2 * pad);
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(fusion_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow_sd, flow_css, (float*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       b, flow_sd, flow_css, (float*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else if (out->dtype == FN2_F16X2)
     hipLaunchKernelGGL(fusion_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       a, b, flow_sd, flow_css, (x2_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       a, b, flow_sd, flow_css, (x2_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(fusion_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       a, b, flow_sd, flow_css, (bf16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       a, b, flow_sd, flow_css, (bf16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else
     hipLaunchKernelGGL(fusion_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       a, b, flow_sd, flow_css, (f16_t*)out->data, out->n, out->h, out->w, out->cs, out->c0);
+                       a, b, flow_sd, flow_css, (f16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   FN2_CHECK_LAUNCH("fusion_input");
   return FN2_OK;
 }

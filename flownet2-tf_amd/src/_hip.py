@@ -55,11 +55,11 @@ PROTOTYPES = {
     "fn2_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(Fn2ConvDesc)]),
     "fn2_conv2d": (_i, [C.POINTER(Fn2ConvDesc), _p]),
     "fn2_upsample_flow": (_i, [_p, _p, _tp, _i, _i, _i, _p]),
-    "fn2_pack_pair": (_i, [_p, _p, _tp, _p]),
-    "fn2_pack_image": (_i, [_p, _i, _tp, _i, _p]),
+    "fn2_pack_pair": (_i, [_p, _p, _tp, _i, _p]),
+    "fn2_pack_image": (_i, [_p, _i, _tp, _i, _i, _p]),
     "fn2_correlation_fused": (_i, [_tp, _tp, _tp, _i, _i, _i, _p]),
-    "fn2_stack_input": (_i, [_p, _p, _p, _tp, _p]),
-    "fn2_fusion_input": (_i, [_p, _p, _p, _p, _tp, _p]),
+    "fn2_stack_input": (_i, [_p, _p, _p, _tp, _i, _p]),
+    "fn2_fusion_input": (_i, [_p, _p, _p, _p, _tp, _i, _p]),
     "fn2_capture_begin": (_i, [_p]),
     "fn2_capture_end": (_i, [_p, C.POINTER(C.c_void_p)]),
     "fn2_graph_launch": (_i, [_p, _p]),

@@ -64,18 +64,15 @@ class Engine:
 
     # ------------------------------------------------------------------ buffers / views
     def _buf(self, name, n, h, w, c, dtype=None, stem=False):
-        """Activation buffer.  dtype=torch.float32: dense fp32 (flow heads, final flows).  stem=True: the
-        packed network input; stays fp32 in split-fp16 engines (read only by the generic stem kernel)."""
+        """Activation buffer.  dtype=torch.float32: dense fp32 (flow heads, final flows).  stem=True: a
+        packed network input (few channels, spatially pre-padded by its builder kernel)."""
         # channel stride: multiples of 64 keep every consumer on the LDS-DMA conv kernel
         # (a tap's channel run is then whole 128-byte lines); small stems stay at multiples of 8
         cs = (_round_up(c, 64) if c > 32 else _round_up(c, 8)) if dtype is None else c
         t = torch.zeros((n, h, w, cs), dtype=self.tdtype if dtype is None else dtype, device=self.device)
         assert name not in self.bufs, name
         self.bufs[name] = t
-        code = self.act_code if dtype is None else _hip.FN2_F32
-        if stem and self.act_code == _hip.FN2_F16X2:
-            code = _hip.FN2_F32
-        self.code_of[t.data_ptr()] = code
+        self.code_of[t.data_ptr()] = self.act_code if dtype is None else _hip.FN2_F32
         return t
 
     def _code(self, buf):
@@ -151,6 +148,46 @@ class Engine:
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         taps = k * k if kind == "conv" else 4
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * taps * cin * cout))
+
+    def _conv_stem(self, scope, spec, sbuf, dst):
+        """First layer of a network on its pre-padded few-channel input: kind-2 row-run convolution
+        (the kw taps x cs channels of a kernel row are one contiguous run of whole 128-byte lines)."""
+        name, kind, k, stride, pad, cin, cout, act = spec
+        dbuf, dc0, dc = dst
+        assert kind == "conv" and dc == cout
+        cs = sbuf.shape[3]
+        in_code = self._code(sbuf)
+        esz = 2 if in_code in (_hip.FN2_BF16, _hip.FN2_F16) else 4
+        run = _round_up(k * cs, 128 // esz)
+        plan = _hip.conv_plan(in_code, run, cout)
+        assert plan.layout == 1, (scope, name)
+        packed, cin_pad, cout_pad, kpad = W.pack_stem(self.weights[f"{scope}/{name}/weights"], cs, run,
+                                                      plan.cout_tile, plan.layout)
+        bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
+        out_scale = 1.0
+        if plan.wgt_dtype == _hip.FN2_F16X2:
+            k2 = int(math.floor(math.log2(1024.0 / float(abs(packed).max()))))
+            packed, out_scale = packed * (2.0 ** k2), 2.0 ** (-k2)
+        wdev = W.packed_to_device(packed, plan.wgt_dtype, self.device)
+        d = _hip.Fn2ConvDesc()
+        d.inp = self._v(sbuf, cs, 0)
+        d.out = self._v(dbuf, dc, dc0)
+        d.wgt = wdev.data_ptr()
+        d.bias = bias.data_ptr()
+        d.kind = 2
+        d.kh = d.kw = k
+        d.stride, d.pad = stride, 0
+        d.act = _hip.ACT_LEAKY if act else _hip.ACT_NONE
+        d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
+        d.wgt_layout = plan.layout
+        d.out_scale = out_scale
+        self.keep += [d, wdev, bias]
+        self.conv_descs.append(d)
+        tn = _TNAME[self.dtype_name]
+        self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
+                 kernel=f"conv_igemm2_kernel<{tn}, {tn}, {'2, 2' if plan.cout_tile == 128 else '1, 4'}>")
+        n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
+        self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * k * k * cin * cout))
 
     def _upflow(self, scope, name, src_f32, dst):
         dbuf, dc0, dc = dst
@@ -231,7 +268,7 @@ class Engine:
         L = {s[0]: s for s in netdefs.flownet_s_layers(cin)}
         cats = self._alloc_cats(tag, N)
         c1 = self._buf(f"{tag}/conv1", N, H // 2, W_ // 2, 64)
-        self._conv(scope, L["conv1"], (x, 0, cin), (c1, 0, 64))
+        self._conv_stem(scope, L["conv1"], x, (c1, 0, 64))
         self._conv(scope, L["conv2"], (c1, 0, 64), (cats[2], 0, 128))
         c3 = self._buf(f"{tag}/conv3", N, H // 8, W_ // 8, 256)
         self._conv(scope, L["conv3"], (cats[2], 0, 128), (c3, 0, 256))
@@ -246,13 +283,13 @@ class Engine:
         N, H, W_ = self.N, self.H, self.W
         L = {s[0]: s for s in netdefs.flownet_c_layers()}
         cats = self._alloc_cats(tag, N)
-        x2 = self._buf(f"{tag}/images", 2 * N, H, W_, 3, stem=True)
+        x2 = self._buf(f"{tag}/images", 2 * N, H + 6, W_ + 6, 3, stem=True)  # pad(.., 3) baked in, :30-34
         v = self._v(x2, 3, 0)
         self.keep.append(v)
-        self._op(f"{tag}/pack_a", self.lib.fn2_pack_image, _hip.ptr(self.in_a), N, C.byref(v), 0)
-        self._op(f"{tag}/pack_b", self.lib.fn2_pack_image, _hip.ptr(self.in_b), N, C.byref(v), N)
+        self._op(f"{tag}/pack_a", self.lib.fn2_pack_image, _hip.ptr(self.in_a), N, C.byref(v), 0, 3)
+        self._op(f"{tag}/pack_b", self.lib.fn2_pack_image, _hip.ptr(self.in_b), N, C.byref(v), N, 3)
         c1 = self._buf(f"{tag}/conv1", 2 * N, H // 2, W_ // 2, 64)
-        self._conv(scope, L["conv1"], (x2, 0, 3), (c1, 0, 64))
+        self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64))
         c2b = self._buf(f"{tag}/conv_b_2", N, H // 4, W_ // 4, 128)
         self._conv(scope, L["conv2"], (c1[:N], 0, 64), (cats[2], 0, 128))  # conv_a_2 = the level-2 skip, :105
         self._conv(scope, L["conv2"], (c1[N:], 0, 64), (c2b, 0, 128))
@@ -280,7 +317,7 @@ class Engine:
         L = {s[0]: s for s in netdefs.flownet_sd_layers()}
         cats = self._alloc_cats(tag, N)
         c0 = self._buf(f"{tag}/conv0", N, H, W_, 64)
-        self._conv(scope, L["conv0"], (x, 0, 6), (c0, 0, 64))
+        self._conv_stem(scope, L["conv0"], x, (c0, 0, 64))
         c1 = self._buf(f"{tag}/conv1", N, H // 2, W_ // 2, 64)
         self._conv(scope, L["conv1"], (c0, 0, 64), (c1, 0, 64))
         c1_1 = self._buf(f"{tag}/conv1_1", N, H // 2, W_ // 2, 128)
@@ -296,19 +333,20 @@ class Engine:
         preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], 0.05)  # flownet_sd.py:106-110
         return preds
 
-    def _pair_input(self, tag):
-        x = self._buf(f"{tag}/pair", self.N, self.H, self.W, 6, stem=True)
+    def _pair_input(self, tag, pad):
+        """[a | b] with the stem's zero border of `pad` pixels baked in (flownet_s.py:24,39)."""
+        x = self._buf(f"{tag}/pair", self.N, self.H + 2 * pad, self.W + 2 * pad, 6, stem=True)
         v = self._v(x, 6, 0)
         self.keep.append(v)
-        self._op(f"{tag}/pack_pair", self.lib.fn2_pack_pair, _hip.ptr(self.in_a), _hip.ptr(self.in_b), C.byref(v))
+        self._op(f"{tag}/pack_pair", self.lib.fn2_pack_pair, _hip.ptr(self.in_a), _hip.ptr(self.in_b), C.byref(v), pad)
         return x
 
     def _stacked_input(self, tag, flow):
-        x = self._buf(f"{tag}/stack", self.N, self.H, self.W, 16, stem=True)
+        x = self._buf(f"{tag}/stack", self.N, self.H + 6, self.W + 6, 16, stem=True)
         v = self._v(x, 12, 0)
         self.keep.append(v)
         self._op(f"{tag}/stack_input", self.lib.fn2_stack_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
-                 _hip.ptr(flow), C.byref(v))  # flow_warp + brightness error + concat, flownet_cs.py:21-36
+                 _hip.ptr(flow), C.byref(v), 3)  # flow_warp + brightness error + concat, flownet_cs.py:21-36
         return x
 
     def _net_cs(self, scope, tag):
@@ -323,16 +361,16 @@ class Engine:
         """FlowNet2.model (flownet2.py:18-105)."""
         N, H, W_ = self.N, self.H, self.W
         css = self._net_css(scope + "/FlowNetCSS", tag + "/CSS")
-        sd = self._net_sd(scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD"))
+        sd = self._net_sd(scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD", 1))
         L = {s[0]: s for s in netdefs.fusion_layers()}
-        xf = self._buf(f"{tag}/fusion_in", N, H, W_, 16, stem=True)
+        xf = self._buf(f"{tag}/fusion_in", N, H + 2, W_ + 2, 16, stem=True)
         v = self._v(xf, 11, 0)
         self.keep.append(v)
         self._op(f"{tag}/fusion_input", self.lib.fn2_fusion_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
-                 _hip.ptr(sd["flow"]), _hip.ptr(css["flow"]), C.byref(v))
+                 _hip.ptr(sd["flow"]), _hip.ptr(css["flow"]), C.byref(v), 1)
         cat0 = self._buf(f"{tag}/concat0", N, H, W_, 82)
         cat1 = self._buf(f"{tag}/concat1", N, H // 2, W_ // 2, 162)
-        self._conv(scope, L["fuse_conv0"], (xf, 0, 11), (cat0, 0, 64))
+        self._conv_stem(scope, L["fuse_conv0"], xf, (cat0, 0, 64))
         f1 = self._buf(f"{tag}/fuse_conv1", N, H // 2, W_ // 2, 64)
         self._conv(scope, L["fuse_conv1"], (cat0, 0, 64), (f1, 0, 64))
         self._conv(scope, L["fuse_conv1_1"], (f1, 0, 64), (cat1, 0, 128))
@@ -360,11 +398,11 @@ class Engine:
     def _build(self):
         m = self.model
         if m == "FlowNetS":
-            return self._net_s("FlowNetS", "S", self._pair_input("S"), 6)
+            return self._net_s("FlowNetS", "S", self._pair_input("S", 3), 6)
         if m == "FlowNetC":
             return self._net_c("FlowNetC", "C")
         if m == "FlowNetSD":
-            return self._net_sd("FlowNetSD", "SD", self._pair_input("SD"))
+            return self._net_sd("FlowNetSD", "SD", self._pair_input("SD", 1))
         if m == "FlowNetCS":
             return self._net_cs("FlowNetCS", "CS")
         if m == "FlowNetCSS":

@@ -81,6 +81,22 @@ def pack_conv(w_hwio, cout_tile, kstep_elems, cin_pad=None, layout=0):
     return out, cin_pad, cout_pad, kpad
 
 
+def pack_stem(w_hwio, cs, run_pad, cout_tile, layout=1):
+    """kind-2 (row-run) stem: [kh,kw,Cin,Cout] -> [cout_pad][kh*run_pad] with k = ky*run_pad + kx*cs + c
+    (cs = channel stride of the pre-padded input buffer, run_pad >= kw*cs whole 128-byte lines)."""
+    kh, kw, cin, cout = w_hwio.shape
+    assert cin <= cs and run_pad >= kw * cs
+    cout_pad = _round_up(cout, cout_tile)
+    p = np.zeros((cout_pad, kh, run_pad), np.float32)
+    wt = np.transpose(w_hwio, (3, 0, 1, 2))  # [cout, kh, kw, cin]
+    for kx in range(kw):
+        p[:cout, :, kx * cs:kx * cs + cin] = wt[:, :, kx, :]
+    out = p.reshape(cout_pad, kh * run_pad)
+    if layout == 1:
+        out = _permute_rows64(out)
+    return out, run_pad, cout_pad, kh * run_pad
+
+
 def pack_deconv(w_hwoi, cout_tile, kstep_elems, cin_pad=None, layout=0):
     """[4,4,Cout,Cin] (HW-O-I) -> [4 phases][cout_pad][kpad]: phase (a,b) is the 2x2 stride-1
     convolution with taps (ty,tx) <- (ky,kx) = (3-a-2ty, 3-b-2tx) producing output pixels (2y+a, 2x+b)."""

@@ -122,6 +122,11 @@ int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in
  *   kind 0: slim.conv2d(pad(x,p), Cout, k, stride, 'VALID')        (flownet_s.py:39-50)
  *   kind 1: antipad(slim.conv2d_transpose(x, Cout, 4, 2, 'VALID')) (flownet_s.py:53-63), computed as
  *           four 2x2 stride-1 phase convolutions; no bias in the reference.
+ *   kind 2: the same convolution as kind 0 for the few-channel network inputs (3/6/11/12 channels): the
+ *           input view is the WHOLE pre-padded buffer [n, H+2p, W+2p, cs] (in.c == in.cs, in.c0 == 0,
+ *           desc.pad == 0), and the kw horizontal taps x cs channels of one kernel row are read as ONE
+ *           contiguous run of cin_pad >= kw*cs channels (packed weight k = ky*cin_pad + kx*cs + c, zero
+ *           beyond kw*cs), so a 7x7x3 stem costs K = 7*64 instead of 49*8..64 and runs on the LDS-DMA kernel.
  * `wgt` is the layer's weight pre-packed by fn2_pack_* layout rules (see DESIGN.md "weights"):
  *   [phase][cout_pad][kpad] elements of in.dtype, k = (tap, channel) with channels padded to a
  *   multiple of 8, kpad a multiple of the k-step; cout_pad a multiple of the block's cout tile (fn2_conv2d_plan). */
@@ -130,7 +135,7 @@ typedef struct {
   fn2_tensor out;      /* out.c = Cout; out.dtype may be FN2_F32 while in is bf16 (flow heads) */
   const void* wgt;
   const float* bias;   /* [Cout] fp32 or NULL */
-  int32_t kind;        /* 0 conv, 1 deconv 4x4 s2 crop 1 */
+  int32_t kind;        /* 0 conv, 1 deconv 4x4 s2 crop 1, 2 stem row-run conv (see fn2_conv2d) */
   int32_t kh, kw, stride, pad;
   int32_t act;         /* fn2_act */
   int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */
@@ -167,11 +172,15 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream);
 int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, int n, int h, int wd,
                       void* stream);
 
-/* images fp32 [n,h,w,3] x2 -> out view with 6 (pad 8) channels [a | b | 0 0]  (flownet_s.py:24) */
-int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, void* stream);
+/* The four "network input" builders below write the INTERIOR of a view whose h, w include a zero border of
+ * `pad` pixels on every side (allocated zero by the caller, never written): the reference's pad() in front
+ * of the stem convolution (utils.py:408-412) is baked into the buffer, so the stem can run as a kind-2
+ * row-run convolution.  pad = 0 gives a dense tensor.
+ * images fp32 [n,h,w,3] x2 -> out view with 6 (pad 8) channels [a | b | 0 0]  (flownet_s.py:24) */
+int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, int pad, void* stream);
 /* image fp32 [n_img,h,w,3] -> batch rows [n0, n0+n_img) of the out view, 3 (pad 8) channels
  * (the siamese towers of FlowNetC run as one 2N batch, flownet_c.py:30-37) */
-int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, void* stream);
+int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, int pad, void* stream);
 
 /* FlowNetC correlation inside the engine: a, b views over conv3 features (C multiple of 32),
  * out = LeakyReLU(correlation(a, b, 1, md, 1, s2, md)) written into a channel slice
@@ -181,13 +190,13 @@ int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_te
 
 /* Stacked-net input (flownet_cs.py:21-36): out view (16-channel padded) =
  * [a(3) | b(3) | warp(b, flow)(3) | flow*0.05(2) | sqrt(sum_c (a-warp)^2)(1) | 0...]. */
-int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out,
+int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out, int pad,
                     void* stream);
 
 /* FlowNet2 fusion input (flownet2.py:25-47): out view (16-channel padded) =
  * [a(3) | flow_sd(2) | flow_css(2) | |sd| | |css| | |a-warp(b,sd)| | |a-warp(b,css)| | 0...]. */
 int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const float* flow_css,
-                     const fn2_tensor* out, void* stream);
+                     const fn2_tensor* out, int pad, void* stream);
 
 /* ---------------------------------------------------------------- launch-graph helpers (hipGraph) */
 int fn2_capture_begin(void* stream);

@@ -233,6 +233,52 @@ def test_split_fp16_stem_deconv_head():
     np.testing.assert_allclose(goth, wanth, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16x2", "bf16"])
+@pytest.mark.parametrize("k,stride,cin,cs", [(7, 2, 3, 8), (7, 2, 12, 16), (3, 1, 6, 8), (3, 1, 11, 16)])
+def test_stem_rowrun_conv(dtype, k, stride, cin, cs):
+    """kind 2: the network stems (flownet_c.py:30, flownet_s.py:39, flownet_sd.py:29, flownet2.py:61) on their
+    pre-padded few-channel input, one contiguous (kw x cs) run per kernel row."""
+    from src import _hip, weights as W
+    lib = _hip.lib()
+    pad = k // 2
+    N, H, Wd, cout = 2, 16, 24, 64
+    x = rnd((N, H, Wd, cin), 30)
+    w = rnd((k, k, cin, cout), 31, (2.0 / (k * k * cin)) ** 0.5)
+    b = rnd((cout,), 32, 0.1)
+    if dtype == "bf16":
+        x = torch.from_numpy(x).bfloat16().float().numpy()
+        w = torch.from_numpy(w).bfloat16().float().numpy()
+    want = refnn.conv2d(x, w, b, stride=stride, padding=pad, activation=refnn.leaky_relu)
+    xp = np.zeros((N, H + 2 * pad, Wd + 2 * pad, cs), np.float32)
+    xp[:, pad:pad + H, pad:pad + Wd, :cin] = x
+    xin = _to_dev(xp, dtype)
+    code = _CODE[dtype]
+    esz = 2 if code in (1, 2) else 4
+    line = 128 // esz
+    run = (k * cs + line - 1) // line * line
+    plan = _hip.conv_plan(code, run, cout)
+    assert plan.layout == 1
+    packed, cin_pad, cout_pad, kpad = W.pack_stem(w, cs, run, plan.cout_tile, plan.layout)
+    scale = 1.0
+    if plan.wgt_dtype == 3:
+        k2 = int(np.floor(np.log2(1024.0 / np.abs(packed).max())))
+        packed, scale = packed * 2.0 ** k2, 2.0 ** -k2
+    wdev = W.packed_to_device(packed, plan.wgt_dtype, "cuda")
+    bdev = torch.from_numpy(b).cuda()
+    oh, ow = want.shape[1], want.shape[2]
+    out = _to_dev(np.zeros((N, oh, ow, 64), np.float32), dtype)
+    d = _hip.Fn2ConvDesc()
+    d.inp, d.out = _hip.view(xin, cs, 0, code), _hip.view(out, cout, 0, code)
+    d.wgt, d.bias = wdev.data_ptr(), bdev.data_ptr()
+    d.kind, d.kh, d.kw, d.stride, d.pad, d.act = 2, k, k, stride, 0, 1
+    d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout, d.out_scale = cin_pad, cout_pad, kpad, plan.layout, scale
+    _hip.check(lib.fn2_conv2d(C.byref(d), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    got = _from_dev(out, code)
+    tol = 1e-2 if dtype == "bf16" else 2e-5
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
+
+
 def test_upsample_flow_matches_oracle():
     from src import _hip
     lib = _hip.lib()
