@@ -263,6 +263,12 @@ static bool corr_fast_ok(int C, int esz, int k, int md, int s1, int s2, int pad)
   return nbt <= CORR_NBT && (64 + 2 * md) <= CORR_WIN * 16 && lo / 16 == 0;
 }
 
+// corr2.hip
+bool corr2_ok(int C, int dtype, int md, int s2, long b_bytes);
+int launch_corr2(const void* a, int a_cs, int a_c0, const void* b, int b_cs, int b_c0, void* out, int out_cs,
+                 int out_c0, int in_dtype, int out_dtype, int N, int H, int W, int C, int md, int s2, int gr, int gw,
+                 int act, hipStream_t s);
+
 }  // namespace fn2
 
 using namespace fn2;
@@ -279,6 +285,9 @@ int fn2_correlation_f32(const float* a, const float* b, float* out, int n, int h
   int oh, ow, gr, gw;
   int rc = correlation_geometry(h, w, k, md, s1, s2, pad, &oh, &ow, &gr, &gw);
   if (rc) return rc;
+  if (k == 1 && s1 == 1 && pad == md && corr2_ok(c, FN2_F32, md, s2, (long)n * h * w * c * 4))
+    return launch_corr2(a, c, 0, b, c, 0, out, gw * gw, 0, FN2_F32, FN2_F32, n, h, w, c, md, s2, gr, gw, FN2_ACT_NONE,
+                        (hipStream_t)stream);
   if (!corr_fast_ok(c, 4, k, md, s1, s2, pad))
     return fn2_correlation_generic_f32(a, b, out, n, h, w, c, k, md, s1, s2, pad, stream);
   CorrArgs g;
@@ -308,6 +317,10 @@ int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_te
   FN2_REQUIRE((a->cs * esz) % 16 == 0 && (a->c0 * esz) % 16 == 0 && (b->cs * esz) % 16 == 0 &&
                   (b->c0 * esz) % 16 == 0,
               "correlation_fused: feature views must be 16-byte aligned");
+  FN2_REQUIRE(out->dtype == a->dtype || out->dtype == FN2_F32, "correlation_fused: bad output dtype");
+  if (corr2_ok(a->c, a->dtype, md, s2, (long)b->n * b->h * b->w * b->cs * esz))
+    return launch_corr2(a->data, a->cs, a->c0, b->data, b->cs, b->c0, out->data, out->cs, out->c0, a->dtype,
+                        out->dtype, a->n, a->h, a->w, a->c, md, s2, gr, gw, act, (hipStream_t)stream);
   if (!corr_fast_ok(a->c, esz, 1, md, 1, s2, md))
     return fail(FN2_ERR_UNSUPPORTED, "correlation_fused: C=%d md=%d s2=%d not covered by the MFMA kernel", a->c, md, s2);
   FN2_REQUIRE(out->dtype == a->dtype || out->dtype == FN2_F32, "correlation_fused: bad output dtype");

@@ -302,7 +302,7 @@ class Engine:
         self.keep += [va, vb, vo]
         tn = _TNAME[self.dtype_name]
         self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
-                 _hip.ACT_LEAKY, kernel=f"corr_mfma_kernel<{tn}, {tn}, {8 if self.dtype_name in ('bf16', 'f16') else 16}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
+                 _hip.ACT_LEAKY, kernel=f"corr2_kernel<{tn}, {tn}, {4 if self.dtype_name in ('bf16', 'f16') else 8}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
         self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
         self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
         self._conv(scope, L["conv3_1"], (net, 0, 473), (cats[3], 0, 256))
