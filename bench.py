@@ -108,7 +108,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "f16x2"])
+    ap.add_argument("--dtype", default="f16x2", choices=["f32", "bf16", "f16", "f16x2"],
+                    help="f16x2 (default) and f32 meet the 1e-3 px parity bar; bf16/f16 do not")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-launch ms and TFLOP/s to stderr")
@@ -192,7 +193,9 @@ def main():
             "metric": "forward pairs/sec at 512x384 (%s)" % args.model, "value": round(pairs_s, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "ms_per_pair": round(ms_step / args.batch, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f16x2": "f16x2 (split fp16 hi+lo operands, 3 fp16 MFMAs per product, fp32 accumulate)"}.get(
+                args.dtype, args.dtype),
             "data": "synthetic", "config": {"workload": "%s forward, batch=%d synthetic %dx%d pairs per GPU, "
                                             "seeded synthetic weights" % (args.model, args.batch, args.width,
                                                                           args.height),

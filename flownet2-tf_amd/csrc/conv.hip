@@ -449,19 +449,28 @@ __global__ void __launch_bounds__(256) upsample_flow_kernel(const float* __restr
   }
 }
 
-// images fp32 [n,h,w,3] -> channels [c_dst, c_dst+3) of the interior of a view padded by `pad` pixels
-template <typename OutT>
-__global__ void __launch_bounds__(256) pack_image_kernel(const float* __restrict__ img, OutT* __restrict__ out,
-                                                         int n, int h, int w, int n0, int pad, int out_cs, int c_dst) {
+// images fp32 [n,h,w,3] (x NIMG) -> the first 8 channels [img0 rgb | img1 rgb | 0 0] (NIMG = 2) or
+// [rgb | 0 x5] (NIMG = 1) of the interior of a view padded by `pad` pixels: one lane per pixel, one
+// 8-channel group store (the zero channels are the buffer's own padding channels).
+template <typename OutT, int NIMG>
+__global__ void __launch_bounds__(256) pack_image_kernel(const float* __restrict__ img0, const float* __restrict__ img1,
+                                                         OutT* __restrict__ out, int n, int h, int w, int n0, int pad,
+                                                         int out_cs, int c0) {
   const long npix = (long)n * h * w;
   const int hp = h + 2 * pad, wp = w + 2 * pad;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % w), y = (int)((i / w) % h), nn = (int)(i / w / h);
-    const float* s = img + i * 3;
-    OutT* d = out + (((size_t)(n0 + nn) * hp + y + pad) * wp + x + pad) * out_cs + c_dst;
-    store_elem<OutT>(d, s[0]);
-    store_elem<OutT>(d + 1, s[1]);
-    store_elem<OutT>(d + 2, s[2]);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    v[0] = img0[i * 3]; v[1] = img0[i * 3 + 1]; v[2] = img0[i * 3 + 2];
+    if (NIMG == 2) { v[3] = img1[i * 3]; v[4] = img1[i * 3 + 1]; v[5] = img1[i * 3 + 2]; }
+    OutT* d = out + (((size_t)(n0 + nn) * hp + y + pad) * wp + x + pad) * out_cs + c0;
+    if constexpr (is_x2<OutT>::value) {
+      uint4* q = reinterpret_cast<uint4*>(d);
+      split8(v, q[0], q[1]);
+    } else {
+      store_vec<OutT, 4>(d, v);
+      store_vec<OutT, 4>(d + 4, v + 4);
+    }
   }
 }
 
@@ -477,6 +486,26 @@ static int check_view(const fn2_tensor* t, const char* what) {
   FN2_REQUIRE(t->dtype >= FN2_F32 && t->dtype <= FN2_F16X2, "%s: bad dtype", what);
   FN2_REQUIRE(t->n >= 1 && t->h >= 1 && t->w >= 1 && t->c >= 1, "%s: bad dims", what);
   FN2_REQUIRE(t->c0 >= 0 && t->c0 + t->c <= t->cs, "%s: channel slice outside the buffer", what);
+  return FN2_OK;
+}
+
+template <int NIMG>
+static int pack_imgs(const float* i0, const float* i1, const fn2_tensor* out, int n, int n0, int pad, void* stream) {
+  FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "pack: bad border");
+  FN2_REQUIRE(out->c0 % 8 == 0 && out->cs % 8 == 0 && out->c0 + 8 <= out->cs, "pack: needs an 8-channel aligned slot");
+  const int h = out->h - 2 * pad, w = out->w - 2 * pad;
+  const long npix = (long)n * h * w;
+  const dim3 g(grid_for(npix, 256)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (out->dtype == FN2_F32)
+    hipLaunchKernelGGL((pack_image_kernel<float, NIMG>), g, b, 0, s, i0, i1, (float*)out->data, n, h, w, n0, pad, out->cs, out->c0);
+  else if (out->dtype == FN2_F16X2)
+    hipLaunchKernelGGL((pack_image_kernel<x2_t, NIMG>), g, b, 0, s, i0, i1, (x2_t*)out->data, n, h, w, n0, pad, out->cs, out->c0);
+  else if (out->dtype == FN2_BF16)
+    hipLaunchKernelGGL((pack_image_kernel<bf16_t, NIMG>), g, b, 0, s, i0, i1, (bf16_t*)out->data, n, h, w, n0, pad, out->cs, out->c0);
+  else
+    hipLaunchKernelGGL((pack_image_kernel<f16_t, NIMG>), g, b, 0, s, i0, i1, (f16_t*)out->data, n, h, w, n0, pad, out->cs, out->c0);
+  FN2_CHECK_LAUNCH("pack_image");
   return FN2_OK;
 }
 
@@ -728,33 +757,12 @@ int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, in
   return FN2_OK;
 }
 
-static int pack_one(const float* img, const fn2_tensor* out, int n, int n0, int c_dst, int pad, void* stream) {
-  FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "pack: bad border");
-  const int h = out->h - 2 * pad, w = out->w - 2 * pad;
-  const long npix = (long)n * h * w;
-  const dim3 g(grid_for(npix, 256)), b(256);
-  hipStream_t s = (hipStream_t)stream;
-  const int cd = out->c0 + c_dst;
-  if (out->dtype == FN2_F32)
-    hipLaunchKernelGGL(pack_image_kernel<float>, g, b, 0, s, img, (float*)out->data, n, h, w, n0, pad, out->cs, cd);
-  else if (out->dtype == FN2_F16X2)
-    hipLaunchKernelGGL(pack_image_kernel<x2_t>, g, b, 0, s, img, (x2_t*)out->data, n, h, w, n0, pad, out->cs, cd);
-  else if (out->dtype == FN2_BF16)
-    hipLaunchKernelGGL(pack_image_kernel<bf16_t>, g, b, 0, s, img, (bf16_t*)out->data, n, h, w, n0, pad, out->cs, cd);
-  else
-    hipLaunchKernelGGL(pack_image_kernel<f16_t>, g, b, 0, s, img, (f16_t*)out->data, n, h, w, n0, pad, out->cs, cd);
-  FN2_CHECK_LAUNCH("pack_image");
-  return FN2_OK;
-}
-
 int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, int pad, void* stream) {
   FN2_REQUIRE(a && b, "pack_pair: null pointer");
   int rc = check_view(out, "pack_pair output");
   if (rc) return rc;
   FN2_REQUIRE(out->c == 6, "pack_pair: output view must have 6 channels");
-  rc = pack_one(a, out, out->n, 0, 0, pad, stream);
-  if (rc) return rc;
-  return pack_one(b, out, out->n, 0, 3, pad, stream);
+  return pack_imgs<2>(a, b, out, out->n, 0, pad, stream);
 }
 
 int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, int pad, void* stream) {
@@ -763,7 +771,7 @@ int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, i
   if (rc) return rc;
   FN2_REQUIRE(out->c == 3, "pack_image: output view must have 3 channels");
   FN2_REQUIRE(n_img >= 1 && n0 >= 0 && n0 + n_img <= out->n, "pack_image: rows [n0, n0+n_img) outside the buffer");
-  return pack_one(img, out, n_img, n0, 0, pad, stream);
+  return pack_imgs<1>(img, nullptr, out, n_img, n0, pad, stream);
 }
 
 }  // extern "C"
