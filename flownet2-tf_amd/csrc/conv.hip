@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
   const int phase = blockIdx.z / p.splitk, split = blockIdx.z - phase * p.splitk;
   if (p.deconv) {
     const int a = phase >> 1, b = phase & 1;
-    pad_y = 1 - a; pad_x = 1 - b; oy_off = a; ox_off = b; osc = 2;
+    pad_y = a ? p.ph_pad1 : p.ph_pad0; pad_x = b ? p.ph_pad1 : p.ph_pad0; oy_off = a; ox_off = b; osc = 2;
     wgt += (size_t)phase * p.cout_pad * p.ksteps * 4 * CH;
   }
   const int kt0 = split * p.kper;
@@ -220,13 +220,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
     for (int t = 0; t < TC; ++t) {
       float v[4];
+      const int co = cout_base + t * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = acc[t][pt][r] * p.out_scale + bias[t][r];
+        if constexpr (sizeof(OutT) == 4 && !is_x2<OutT>::value) {
+          if (p.accum && co + r < p.Cout) x += reinterpret_cast<const float*>(po)[co + r];
+        }
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
         v[r] = x;
       }
-      const int co = cout_base + t * 4;
       if (p.vec_ok && co + 3 < p.Cout) {
         store4<OutT>(po + co, v[0], v[1], v[2], v[3]);
       } else {
@@ -243,7 +246,7 @@ template <typename OutT>
 __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                               OutT* __restrict__ out, long npix, int ws_cs, int splitk,
                                                               int Cout, int out_cs, int out_c0, int act, int vec_ok,
-                                                              float out_scale) {
+                                                              float out_scale, int accum) {
   const int groups = ws_cs / 4;
   const long total = npix * groups;
   const size_t slab = (size_t)npix * ws_cs;
@@ -256,13 +259,16 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     float r[4] = {v.x, v.y, v.z, v.w};
+    OutT* po = out + (size_t)pix * out_cs + out_c0 + co;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       r[j] *= out_scale;
       if (bias != nullptr && co + j < Cout) r[j] += bias[co + j];
+      if constexpr (sizeof(OutT) == 4 && !is_x2<OutT>::value) {
+        if (accum && co + j < Cout) r[j] += reinterpret_cast<const float*>(po)[j];
+      }
       if (act == FN2_ACT_LEAKY) r[j] = leaky(r[j]);
     }
-    OutT* po = out + (size_t)pix * out_cs + out_c0 + co;
     if (vec_ok && co + 3 < Cout) {
       store4<OutT>(po, r[0], r[1], r[2], r[3]);
     } else {
@@ -555,7 +561,8 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   rc = check_view(&d->out, "conv2d output");
   if (rc) return rc;
   FN2_REQUIRE(d->wgt, "conv2d: null weights");
-  FN2_REQUIRE(d->kind >= 0 && d->kind <= 2, "conv2d: kind must be 0 (conv), 1 (deconv) or 2 (stem row-run conv)");
+  FN2_REQUIRE(d->kind >= 0 && d->kind <= 3,
+              "conv2d: kind must be 0 (conv), 1 (deconv k4 s2 crop 1), 2 (stem row-run conv) or 3 (transpose of a stride-2 conv)");
   FN2_REQUIRE(d->in.n == d->out.n, "conv2d: batch mismatch");
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cin_pad >= d->in.c, "conv2d: cin_pad must be a multiple of 8 >= Cin");
   FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: input channel stride/offset must be multiples of 8");
@@ -591,7 +598,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     FN2_REQUIRE(a.OH >= 1 && a.OW >= 1, "conv2d: kernel does not fit");
     FN2_REQUIRE(d->out.h == a.OH && d->out.w == a.OW, "conv2d: output spatial size %dx%d != expected %dx%d",
                 d->out.h, d->out.w, a.OH, a.OW);
-    a.deconv = 0;
+    a.deconv = 0; a.ph_pad0 = a.ph_pad1 = 0;
   } else if (d->kind == 2) {
     // stem row-run conv: the kw taps x cs channels of a kernel row are one contiguous run of the
     // pre-padded NHWC input; runs past the row end read the next row / out-of-range zeros under zero weights
@@ -605,16 +612,34 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     FN2_REQUIRE(a.OH >= 1 && a.OW >= 1, "stem conv: kernel does not fit");
     FN2_REQUIRE(d->out.h == a.OH && d->out.w == a.OW, "stem conv: output spatial size %dx%d != expected %dx%d",
                 d->out.h, d->out.w, a.OH, a.OW);
-    a.deconv = 0;
-  } else {
+    a.deconv = 0; a.ph_pad0 = a.ph_pad1 = 0;
+  } else if (d->kind == 1) {
     FN2_REQUIRE(d->kh == 4 && d->kw == 4 && d->stride == 2, "deconv: only k=4 s=2 crop 1 (flownet_s.py:53-63)");
     FN2_REQUIRE(d->bias == nullptr, "deconv: the reference transposed convs have no bias (biases_initializer=None)");
     a.KH = 2; a.KW = 2; a.stride = 1; a.pad = 0;
     a.OH = d->in.h; a.OW = d->in.w;
     FN2_REQUIRE(d->out.h == 2 * d->in.h && d->out.w == 2 * d->in.w, "deconv: output must be 2H x 2W");
     a.deconv = 1;
+    a.ph_pad0 = 1; a.ph_pad1 = 0;  // phase a reads rows m-1+a+t, t in {0,1}
+    phases = 4;
+  } else {
+    // kind 3: gradient wrt the input of a stride-2 convolution (kernel k, pad p) = transposed convolution.
+    // Output row 2m+a receives dY rows m+lo_a+t, t in [0,T), T = ceil(k/2), lo_a = ceil((a+p-k+1)/2); the
+    // packed phase weight holds W[ky = a+p-2lo_a-2t] (zero where ky falls outside [0,k)).
+    FN2_REQUIRE(d->stride == 2 && d->kh == d->kw && d->kh >= 1 && d->pad >= 0 && d->bias == nullptr && d->act == FN2_ACT_NONE,
+                "conv-transpose (kind 3): stride 2, square kernel, no bias, no activation");
+    const int T = (d->kh + 1) / 2;
+    a.KH = T; a.KW = T; a.stride = 1; a.pad = 0;
+    a.OH = d->in.h; a.OW = d->in.w;
+    FN2_REQUIRE(d->out.h == 2 * d->in.h && d->out.w == 2 * d->in.w, "conv-transpose: output must be 2H x 2W");
+    a.deconv = 1;
+    auto ceil_half = [](int v) { return v >= 0 ? (v + 1) / 2 : -((-v) / 2); };
+    a.ph_pad0 = -ceil_half(0 + d->pad - d->kh + 1);
+    a.ph_pad1 = -ceil_half(1 + d->pad - d->kh + 1);
     phases = 4;
   }
+  a.accum = d->accumulate ? 1 : 0;
+  if (a.accum) FN2_REQUIRE(d->out.dtype == FN2_F32, "conv2d: accumulate needs an fp32 output");
   const long M = (long)a.N * a.OH * a.OW;
   FN2_REQUIRE(M < (1L << 31), "conv2d: too many output pixels");
   a.M = (int)M;
@@ -719,16 +744,16 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
   if (d->out.dtype == FN2_F32)
     hipLaunchKernelGGL(splitk_finalize_kernel<float>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (float*)a.out, npix,
-                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
+                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
   else if (d->out.dtype == FN2_F16X2)
     hipLaunchKernelGGL(splitk_finalize_kernel<x2_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (x2_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
   else if (d->out.dtype == FN2_BF16)
     hipLaunchKernelGGL(splitk_finalize_kernel<bf16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (bf16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
   else
     hipLaunchKernelGGL(splitk_finalize_kernel<f16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (f16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
   FN2_CHECK_LAUNCH("splitk_finalize");
   return FN2_OK;
 }

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
   if (p.deconv) {
     const int a = phase >> 1, b = phase & 1;
-    pad_y = 1 - a; pad_x = 1 - b; oy_off = a; ox_off = b; osc = 2;
+    pad_y = a ? p.ph_pad1 : p.ph_pad0; pad_x = b ? p.ph_pad1 : p.ph_pad0; oy_off = a; ox_off = b; osc = 2;
     wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
   }
   const int kt0 = split * p.kper;
@@ -267,6 +267,9 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float x = acc[tc][tp][q] * p.out_scale + bias[q];
+        if constexpr (sizeof(OutT) == 4 && !is_x2<OutT>::value) {
+          if (p.accum && cout_base + q < p.Cout) x += reinterpret_cast<const float*>(po)[q];
+        }
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
         v[q] = x;
       }

@@ -32,7 +32,13 @@ class Fn2ConvDesc(C.Structure):
     _fields_ = [("inp", Fn2Tensor), ("out", Fn2Tensor), ("wgt", C.c_void_p), ("bias", C.c_void_p),
                 ("kind", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("act", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
-                ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
+class Fn2BwdwDesc(C.Structure):
+    _fields_ = [("x", Fn2Tensor), ("dy", Fn2Tensor), ("dw", C.c_void_p), ("kind", C.c_int32), ("kh", C.c_int32),
+                ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("cin_pad", C.c_int32),
+                ("cout_pad", C.c_int32), ("kpad", C.c_int32), ("wgt_layout", C.c_int32)]
 
 
 _i, _p, _f = C.c_int, C.c_void_p, C.c_float
@@ -60,6 +66,15 @@ PROTOTYPES = {
     "fn2_correlation_fused": (_i, [_tp, _tp, _tp, _i, _i, _i, _p]),
     "fn2_stack_input": (_i, [_p, _p, _p, _tp, _i, _p]),
     "fn2_fusion_input": (_i, [_p, _p, _p, _p, _tp, _i, _p]),
+    "fn2_epe_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "fn2_leaky_bwd": (_i, [_tp, _tp, _p]),
+    "fn2_bias_grad": (_i, [_tp, _p, _p]),
+    "fn2_gather_f32": (_i, [_p, _p, _p, C.c_int64, _p]),
+    "fn2_adam_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _i, _f, _f, _p]),
+    "fn2_upsample_flow_bwd": (_i, [_tp, _p, _p, _p, _p, _i, _p]),
+    "fn2_head_bwd_filter": (_i, [_tp, _p, _p, _i, _i, _p]),
+    "fn2_head_bwd_data": (_i, [_p, _p, _tp, _i, _i, _p]),
+    "fn2_conv2d_bwd_filter": (_i, [C.POINTER(Fn2BwdwDesc), _p]),
     "fn2_capture_begin": (_i, [_p]),
     "fn2_capture_end": (_i, [_p, C.POINTER(C.c_void_p)]),
     "fn2_graph_launch": (_i, [_p, _p]),

@@ -59,6 +59,7 @@ class Engine:
         self.in_b = torch.zeros_like(self.in_a)
         self.graph = None
         self.conv_descs = []
+        self.layers = []   # one record per parameterised layer, in forward order (used by the trainer)
         self.outputs = self._build()
         self._alloc_workspace()
 
@@ -134,6 +135,9 @@ class Engine:
         d.out_scale = out_scale
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
+        self.layers.append(dict(scope=scope, name=name, kind=d.kind, k=k, stride=stride, pad=pad, cin=cin, cout=cout,
+                                act=bool(act), src=src, dst=dst, desc=d, w=wdev, b=bias, cin_pad=cin_pad,
+                                cout_pad=cout_pad, kpad=kpad, layout=layout, tile=tile, kstep=plan.kstep_elems))
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         if kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1:
             kern = f"flow_head_kernel<{tn}>"
@@ -183,6 +187,10 @@ class Engine:
         d.out_scale = out_scale
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
+        self.layers.append(dict(scope=scope, name=name, kind=2, k=k, stride=stride, pad=pad, cin=cin, cout=cout,
+                                act=bool(act), src=(sbuf, 0, cs), dst=dst, desc=d, w=wdev, b=bias, cin_pad=cin_pad,
+                                cout_pad=cout_pad, kpad=kpad, layout=plan.layout, tile=plan.cout_tile,
+                                kstep=plan.kstep_elems, cs=cs))
         tn = _TNAME[self.dtype_name]
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
                  kernel=f"conv_igemm2_kernel<{tn}, {tn}, {'2, 2' if plan.cout_tile == 128 else '1, 4'}>")
@@ -195,6 +203,7 @@ class Engine:
         v = self._v(dbuf, dc, dc0)
         self.keep += [w, v]
         n, h, wd, _ = src_f32.shape
+        self.layers.append(dict(scope=scope, name=name, kind="upflow", src=src_f32, dst=dst, w=w, b=None, view=v))
         self._op(f"{scope}/{name}", self.lib.fn2_upsample_flow, _hip.ptr(src_f32), _hip.ptr(w), C.byref(v), n, h, wd)
 
     def _resize(self, name, src_f32, scale):

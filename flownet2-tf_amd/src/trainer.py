@@ -1,0 +1,283 @@
+"""FlowNetS training step on one MI355X (+ data-parallel gradient all-reduce over RCCL):
+forward -> multiscale EPE loss -> backward -> Adam, all fp32 on the matrix cores.
+
+Reference semantics (what tf.gradients + tf.train.AdamOptimizer compute for it):
+  loss      FlowNetS.loss, src/flownet_s/flownet_s.py:122-161 -- labels = downsample(0.05*gt) per scale,
+            average_endpoint_error (src/utils.py:209-224), compute_weighted_loss over the 5 scalars
+            (weights .32 .08 .02 .01 .005, /5), + slim L2 regularisers (l2 = 4e-4 on slim.conv2d weights)
+  optimiser Adam(lr from piecewise_constant LONG_SCHEDULE, beta 0.9/0.999, eps 1e-8), src/net.py:1205-1207,
+            :1290-1295; src/training_schedules.py:46-53
+  DP        not in the reference (single GPU).  Here: one process per GPU, each rank runs the step on its
+            shard, ONE all-reduce of the flat gradient buffer, identical Adam on every rank.
+
+Parameters stay in the packed layouts the forward kernels read (Adam is elementwise, so the layout is
+irrelevant to it); filter gradients are produced directly in those layouts; the transposed / phase-decomposed
+copies that the input-gradient convolutions read are refreshed once per step by an index-map gather.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _hip, weights as W
+from .engine import Engine, _round_up
+from .training_schedules import LONG_SCHEDULE
+
+LOSS_WEIGHTS = {6: 0.32, 5: 0.08, 4: 0.02, 3: 0.01, 2: 0.005}
+F32 = _hip.FN2_F32
+
+
+def _index_hwio(rec):
+    """Flat position inside the layer's packed master weight of every element of its reference-layout
+    weight (HWIO for conv, HW-O-I for deconv): pack an enumeration with the same packer and invert it."""
+    kind = rec["kind"]
+    if kind == 1:
+        shape = (4, 4, rec["cout"], rec["cin"])
+        enum = np.arange(1, int(np.prod(shape)) + 1, dtype=np.float64).reshape(shape)
+        pk = W.pack_deconv(enum, rec["tile"], rec["kstep"], rec["cin_pad"], rec["layout"], dtype=np.float64)[0]
+    else:
+        shape = (rec["k"], rec["k"], rec["cin"], rec["cout"])
+        enum = np.arange(1, int(np.prod(shape)) + 1, dtype=np.float64).reshape(shape)
+        if kind == 2:
+            pk = W.pack_stem(enum, rec["cs"], rec["cin_pad"], rec["tile"], rec["layout"], dtype=np.float64)[0]
+        else:
+            pk = W.pack_conv(enum, rec["tile"], rec["kstep"], rec["cin_pad"], rec["layout"], dtype=np.float64)[0]
+    flat = pk.reshape(-1)
+    pos = np.nonzero(flat)[0]
+    inv = np.empty(int(np.prod(shape)), np.int64)
+    inv[flat[pos].astype(np.int64) - 1] = pos
+    return inv.reshape(shape)
+
+
+class FlowNetSTrainer:
+    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8, world_size=1):
+        self.eng = Engine("FlowNetS", weights, batch, height, width, "f32")
+        self.lib, self.dev = self.eng.lib, self.eng.device
+        self.N, self.H, self.W = batch, height, width
+        self.schedule, self.eps, self.world = schedule, eps, world_size
+        self.step_count = 0
+        self.keep = []
+        self.gt = torch.zeros((batch, height, width, 2), dtype=torch.float32, device=self.dev)
+        self.loss_dev = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self._build()
+
+    # ------------------------------------------------------------------ construction
+    def _gbuf(self, buf):
+        """Gradient buffer mirroring an activation buffer (fp32, same shape)."""
+        key = buf.untyped_storage().data_ptr()
+        if key not in self.gbufs:
+            base = self.base_of[key]
+            self.gbufs[key] = torch.zeros_like(base)
+        g = self.gbufs[key]
+        if buf.shape[0] != g.shape[0]:  # batch slice of a 2N buffer (not used by FlowNetS)
+            raise NotImplementedError
+        return g
+
+    def _view(self, buf, c, c0):
+        return _hip.view(buf, c, c0, F32)
+
+    def _build(self):
+        eng = self.eng
+        self.base_of = {b.untyped_storage().data_ptr(): b for b in eng.bufs.values()}
+        self.gbufs = {}
+        layers = eng.layers
+        # ---- parameters and one flat gradient / moment arena (single all-reduce, single memset)
+        params = []  # (tensor, l2 flag)
+        for rec in layers:
+            reg = rec["kind"] in (0, 2)  # slim.conv2d weights (heads included); deconv / upsample / biases are not
+            params.append((rec["w"], reg, rec))
+            if rec.get("b") is not None:
+                params.append((rec["b"], False, None))
+        total = sum(_round_up(t.numel(), 4) for t, _, _ in params)
+        self.grad_arena = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.m_arena = torch.zeros_like(self.grad_arena)
+        self.v_arena = torch.zeros_like(self.grad_arena)
+        self.params = []
+        off = 0
+        for t, reg, rec in params:
+            n = t.numel()
+            g = self.grad_arena[off:off + n]
+            self.params.append(dict(w=t, g=g, m=self.m_arena[off:off + n], v=self.v_arena[off:off + n], reg=reg, n=n))
+            if rec is not None:
+                rec["dw"] = g
+            off += _round_up(n, 4)
+        # map bias tensors to their grads
+        bias_grad = {p["w"].data_ptr(): p["g"] for p in self.params}
+        for rec in layers:
+            if rec.get("b") is not None:
+                rec["db"] = bias_grad[rec["b"].data_ptr()]
+
+        # ---- per-layer backward launches, in reverse forward order
+        self.bwd_ops = []
+        self.gathers = []
+        for rec in reversed(layers):
+            if rec["kind"] == "upflow":
+                self._plan_upflow(rec)
+            elif rec["cout"] == 2:
+                self._plan_head(rec)
+            else:
+                self._plan_conv(rec)
+        eng._alloc_workspace()  # the input-gradient convolutions share the split-K scratch buffer
+        self.refresh_backward_weights()
+
+    def _bwd_data_conv(self, rec, hwio_index, kind, k, stride, pad, g_src, g_dst):
+        """fn2_conv2d launch computing the input gradient: in = gradient of the layer output slice,
+        out = gradient of the layer input slice (accumulated)."""
+        gy_buf, gy_c0, gy_c = g_src
+        gx_buf, gx_c0, gx_c = g_dst
+        cin_b, cout_b = gy_c, gx_c
+        cin_pad = _round_up(cin_b, 8)
+        line = _round_up(cin_b, 32)
+        if gy_c0 + line <= gy_buf.shape[3] and _hip.conv_plan(F32, line, cout_b).layout == 1:
+            cin_pad = line
+        plan = _hip.conv_plan(F32, cin_pad, cout_b)
+        enum = hwio_index.astype(np.float64) + 1.0
+        if kind == 3:
+            pk, cin_pad, cout_pad, kpad = W.pack_conv_transpose_s2(enum, pad, plan.cout_tile, plan.kstep_elems, cin_pad,
+                                                                   plan.layout, dtype=np.float64)
+        else:
+            pk, cin_pad, cout_pad, kpad = W.pack_conv(enum, plan.cout_tile, plan.kstep_elems, cin_pad, plan.layout,
+                                                      dtype=np.float64)
+        gmap = torch.from_numpy((pk.reshape(-1) - 1.0).astype(np.int32)).to(self.dev)
+        wb = torch.zeros(gmap.numel(), dtype=torch.float32, device=self.dev)
+        self.gathers.append((wb, rec["w"], gmap))
+        d = _hip.Fn2ConvDesc()
+        d.inp = self._view(gy_buf, gy_c, gy_c0)
+        d.out = self._view(gx_buf, gx_c, gx_c0)
+        d.wgt, d.bias = wb.data_ptr(), None
+        d.kind, d.kh, d.kw, d.stride, d.pad = kind, k, k, stride, pad
+        d.act = _hip.ACT_NONE
+        d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, plan.layout
+        d.accumulate = 1
+        d.out_scale = 1.0
+        self.keep += [d, wb, gmap]
+        self.eng.conv_descs.append(d)  # shares the split-K workspace
+        return d
+
+    def _plan_conv(self, rec):
+        sbuf, sc0, sc = rec["src"]
+        dbuf, dc0, dc = rec["dst"]
+        gy = self._gbuf(dbuf)
+        ops = []
+        vy, vg = self._view(dbuf, dc, dc0), self._view(gy, dc, dc0)
+        self.keep += [vy, vg]
+        if rec["act"]:
+            ops.append((self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg))))
+        if rec.get("b") is not None:
+            ops.append((self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"]))))
+        bd = _hip.Fn2BwdwDesc()
+        bd.x = self._view(sbuf, sc, sc0)
+        bd.dy = vg
+        bd.dw = rec["dw"].data_ptr()
+        bd.kind, bd.kh, bd.kw, bd.stride, bd.pad = rec["kind"], rec["k"], rec["k"], rec["stride"], \
+            (0 if rec["kind"] == 2 else rec["pad"])
+        bd.cin_pad, bd.cout_pad, bd.kpad, bd.wgt_layout = rec["cin_pad"], rec["cout_pad"], rec["kpad"], rec["layout"]
+        self.keep.append(bd)
+        ops.append((self.lib.fn2_conv2d_bwd_filter, (C.byref(bd),)))
+        if rec["kind"] != 2:  # the stem's input is the image pair: no gradient needed
+            gx = self._gbuf(sbuf)
+            idx = _index_hwio(rec)
+            k, p = rec["k"], rec["pad"]
+            if rec["kind"] == 1:
+                # transposed conv forward -> plain conv k4 s2 p1 backward, HWIO' = Wt[ky,kx,co,ci]
+                d = self._bwd_data_conv(rec, idx, 0, 4, 2, 1, (gy, dc0, dc), (gx, sc0, sc))
+            elif rec["stride"] == 1:
+                rot = np.ascontiguousarray(idx[::-1, ::-1].transpose(0, 1, 3, 2))  # flip taps, swap ci/co
+                d = self._bwd_data_conv(rec, rot, 0, k, 1, k - 1 - p, (gy, dc0, dc), (gx, sc0, sc))
+            else:
+                d = self._bwd_data_conv(rec, idx, 3, k, 2, p, (gy, dc0, dc), (gx, sc0, sc))
+            ops.append((self.lib.fn2_conv2d, (C.byref(d),)))
+        self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
+
+    def _plan_head(self, rec):
+        sbuf, sc0, sc = rec["src"]
+        pf = rec["dst"][0]
+        dpf = self._gbuf(pf)
+        gx = self._gbuf(sbuf)
+        vx, vg = self._view(sbuf, sc, sc0), self._view(dpf, 2, 0)
+        self.keep += [vx, vg]
+        ops = [(self.lib.fn2_head_bwd_filter, (C.byref(vx), _hip.ptr(dpf), _hip.ptr(rec["dw"]), rec["cin_pad"], rec["kpad"])),
+               (self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"])))]
+        vdx = self._view(gx, sc, sc0)
+        self.keep.append(vdx)
+        ops.append((self.lib.fn2_head_bwd_data, (_hip.ptr(dpf), _hip.ptr(rec["w"]), C.byref(vdx), rec["cin_pad"], rec["kpad"])))
+        self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
+
+    def _plan_upflow(self, rec):
+        pf = rec["src"]
+        dbuf, dc0, dc = rec["dst"]
+        vg = self._view(self._gbuf(dbuf), 2, dc0)
+        self.keep.append(vg)
+        ops = [(self.lib.fn2_upsample_flow_bwd, (C.byref(vg), _hip.ptr(pf), _hip.ptr(rec["w"]), _hip.ptr(self._gbuf(pf)),
+                                                 _hip.ptr(rec["dw"]), 1))]
+        self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
+
+    # ------------------------------------------------------------------ step
+    def refresh_backward_weights(self):
+        s = _hip.stream_ptr()
+        for wb, wsrc, gmap in self.gathers:
+            _hip.check(self.lib.fn2_gather_f32(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), s))
+
+    def learning_rate(self, step):
+        lr = self.schedule["learning_rates"]
+        for i, b in enumerate(self.schedule["step_values"]):
+            if step < b:
+                return lr[i]
+        return lr[-1]
+
+    def forward_backward(self, input_a, input_b, gt_flow):
+        """Loss and all parameter gradients (left in self.grad_arena).  Returns the loss as a device scalar."""
+        eng, s = self.eng, _hip.stream_ptr()
+        self.gt.copy_(torch.as_tensor(gt_flow).to(dtype=torch.float32), non_blocking=True)
+        eng.set_inputs(input_a, input_b)
+        self.grad_arena.zero_()
+        for g in self.gbufs.values():
+            g.zero_()
+        self.loss_dev.zero_()
+        eng.launch()
+        # ---- loss and its gradient at the five scales (flownet_s.py:122-158)
+        gts = self.gt * 0.05
+        for lvl, wgt in LOSS_WEIGHTS.items():
+            pred = eng.outputs["predict_flow%d" % lvl]
+            n, h, w, _ = pred.shape
+            label = torch.empty_like(pred)
+            _hip.check(self.lib.fn2_downsample_f32(_hip.ptr(gts), _hip.ptr(label), n, self.H, self.W, 2, h, w, s))
+            _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
+                                                  _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, s))
+            self.keep_label = label
+        # ---- backward
+        for name, ops in self.bwd_ops:
+            for fn, args in ops:
+                rc = fn(*args, s)
+                if rc:
+                    try:
+                        _hip.check(rc)
+                    except Exception as e:
+                        raise type(e)("backward of %s: %s" % (name, e)) from None
+        return self.loss_dev
+
+    def l2_term(self):
+        """0.5*l2*sum |W|^2 over the regularised weights (host-side report only)."""
+        l2 = self.schedule["l2_regularization"]
+        return float(sum(0.5 * l2 * float((p["w"].double() ** 2).sum()) for p in self.params if p["reg"]))
+
+    def apply_gradients(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.all_reduce(self.grad_arena)  # RCCL sum over xGMI; the mean is folded into Adam's grad_scale
+        self.step_count += 1
+        lr = self.learning_rate(self.step_count - 1)
+        b1, b2 = self.schedule["momentum"], self.schedule["momentum2"]
+        l2 = self.schedule["l2_regularization"]
+        s = _hip.stream_ptr()
+        for p in self.params:
+            _hip.check(self.lib.fn2_adam_step(_hip.ptr(p["w"]), _hip.ptr(p["m"]), _hip.ptr(p["v"]), _hip.ptr(p["g"]),
+                                              p["n"], lr, b1, b2, self.eps, self.step_count,
+                                              l2 if p["reg"] else 0.0, 1.0 / self.world, s))
+        self.refresh_backward_weights()
+
+    def train_step(self, input_a, input_b, gt_flow):
+        loss = self.forward_backward(input_a, input_b, gt_flow)
+        self.apply_gradients()
+        return loss

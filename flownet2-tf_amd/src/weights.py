@@ -65,29 +65,29 @@ def _permute_rows64(rows):
     return rows[full]
 
 
-def pack_conv(w_hwio, cout_tile, kstep_elems, cin_pad=None, layout=0):
-    """[kh,kw,Cin,Cout] -> [cout_pad][kpad] fp32 with k = (tap, channel padded to cin_pad)."""
+def pack_conv(w_hwio, cout_tile, kstep_elems, cin_pad=None, layout=0, dtype=np.float32):
+    """[kh,kw,Cin,Cout] -> [cout_pad][kpad] with k = (tap, channel padded to cin_pad)."""
     kh, kw, cin, cout = w_hwio.shape
     cin_pad = _round_up(cin, 8) if cin_pad is None else cin_pad
     assert cin_pad >= cin and cin_pad % 8 == 0
     cout_pad = _round_up(cout, cout_tile)
     kpad = _round_up(kh * kw * cin_pad, kstep_elems)
-    p = np.zeros((cout_pad, kh * kw, cin_pad), np.float32)
+    p = np.zeros((cout_pad, kh * kw, cin_pad), dtype)
     p[:cout, :, :cin] = np.transpose(w_hwio, (3, 0, 1, 2)).reshape(cout, kh * kw, cin)
-    out = np.zeros((cout_pad, kpad), np.float32)
+    out = np.zeros((cout_pad, kpad), dtype)
     out[:, :kh * kw * cin_pad] = p.reshape(cout_pad, -1)
     if layout == 1:
         out = _permute_rows64(out)
     return out, cin_pad, cout_pad, kpad
 
 
-def pack_stem(w_hwio, cs, run_pad, cout_tile, layout=1):
+def pack_stem(w_hwio, cs, run_pad, cout_tile, layout=1, dtype=np.float32):
     """kind-2 (row-run) stem: [kh,kw,Cin,Cout] -> [cout_pad][kh*run_pad] with k = ky*run_pad + kx*cs + c
     (cs = channel stride of the pre-padded input buffer, run_pad >= kw*cs whole 128-byte lines)."""
     kh, kw, cin, cout = w_hwio.shape
     assert cin <= cs and run_pad >= kw * cs
     cout_pad = _round_up(cout, cout_tile)
-    p = np.zeros((cout_pad, kh, run_pad), np.float32)
+    p = np.zeros((cout_pad, kh, run_pad), dtype)
     wt = np.transpose(w_hwio, (3, 0, 1, 2))  # [cout, kh, kw, cin]
     for kx in range(kw):
         p[:cout, :, kx * cs:kx * cs + cin] = wt[:, :, kx, :]
@@ -97,7 +97,7 @@ def pack_stem(w_hwio, cs, run_pad, cout_tile, layout=1):
     return out, run_pad, cout_pad, kh * run_pad
 
 
-def pack_deconv(w_hwoi, cout_tile, kstep_elems, cin_pad=None, layout=0):
+def pack_deconv(w_hwoi, cout_tile, kstep_elems, cin_pad=None, layout=0, dtype=np.float32):
     """[4,4,Cout,Cin] (HW-O-I) -> [4 phases][cout_pad][kpad]: phase (a,b) is the 2x2 stride-1
     convolution with taps (ty,tx) <- (ky,kx) = (3-a-2ty, 3-b-2tx) producing output pixels (2y+a, 2x+b)."""
     kh, kw, cout, cin = w_hwoi.shape
@@ -106,16 +106,50 @@ def pack_deconv(w_hwoi, cout_tile, kstep_elems, cin_pad=None, layout=0):
     assert cin_pad >= cin and cin_pad % 8 == 0
     cout_pad = _round_up(cout, cout_tile)
     kpad = _round_up(4 * cin_pad, kstep_elems)
-    out = np.zeros((4, cout_pad, kpad), np.float32)
+    out = np.zeros((4, cout_pad, kpad), dtype)
     for a in range(2):
         for b in range(2):
-            p = np.zeros((cout_pad, 4, cin_pad), np.float32)
+            p = np.zeros((cout_pad, 4, cin_pad), dtype)
             for ty in range(2):
                 for tx in range(2):
                     p[:cout, ty * 2 + tx, :cin] = w_hwoi[3 - a - 2 * ty, 3 - b - 2 * tx]
-            ph = np.zeros((cout_pad, kpad), np.float32)
+            ph = np.zeros((cout_pad, kpad), dtype)
             ph[:, :4 * cin_pad] = p.reshape(cout_pad, -1)
             out[a * 2 + b] = _permute_rows64(ph) if layout == 1 else ph
+    return out, cin_pad, cout_pad, kpad
+
+
+def pack_conv_transpose_s2(w_hwio, p, cout_tile, kstep_elems, cin_pad, layout, dtype=np.float32):
+    """Weights of fn2_conv2d kind 3 -- the input gradient of a stride-2 convolution with kernel k, pad p and
+    forward weight w_hwio [k,k,Ci,Co]: a transposed convolution whose "input channels" are Co and "output
+    channels" Ci.  Phase (a,b), tap (ty,tx) holds W[ky][kx]^T with ky = a+p-2*lo_a-2*ty, lo_a = ceil((a+p-k+1)/2)
+    (zero where ky is outside [0,k)).  Returns [4][cout_pad][T*T*cin_pad] with cin_pad >= Co, cout_pad >= Ci."""
+    k, _, ci, co = w_hwio.shape
+    T = (k + 1) // 2
+    cout_pad = _round_up(ci, cout_tile)
+    kpad = _round_up(T * T * cin_pad, kstep_elems)
+    assert cin_pad >= co
+
+    def ceil_half(v):
+        return -((-v) // 2)
+
+    out = np.zeros((4, cout_pad, kpad), dtype)
+    for a in range(2):
+        lo_a = ceil_half(a + p - k + 1)
+        for b in range(2):
+            lo_b = ceil_half(b + p - k + 1)
+            ph = np.zeros((cout_pad, T * T, cin_pad), dtype)
+            for ty in range(T):
+                ky = a + p - 2 * lo_a - 2 * ty
+                if not 0 <= ky < k:
+                    continue
+                for tx in range(T):
+                    kx = b + p - 2 * lo_b - 2 * tx
+                    if 0 <= kx < k:
+                        ph[:ci, ty * T + tx, :co] = w_hwio[ky, kx]  # [ci, co]
+            full = np.zeros((cout_pad, kpad), dtype)
+            full[:, :T * T * cin_pad] = ph.reshape(cout_pad, -1)
+            out[a * 2 + b] = _permute_rows64(full) if layout == 1 else full
     return out, cin_pad, cout_pad, kpad
 
 

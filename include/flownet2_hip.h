@@ -127,6 +127,9 @@ int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in
  *           desc.pad == 0), and the kw horizontal taps x cs channels of one kernel row are read as ONE
  *           contiguous run of cin_pad >= kw*cs channels (packed weight k = ky*cin_pad + kx*cs + c, zero
  *           beyond kw*cs), so a 7x7x3 stem costs K = 7*64 instead of 49*8..64 and runs on the LDS-DMA kernel.
+ *   kind 3: the transposed convolution that is the input-gradient of a stride-2 kind-0 layer (kh = kw = k,
+ *           pad = p of THAT layer): four phases of ceil(k/2)^2 taps; packed weight [4][cout_pad][T*T*cin_pad]
+ *           with tap (ty,tx) of phase (a,b) = W[ky = a+p-2*lo_a-2*ty][kx likewise], lo_a = ceil((a+p-k+1)/2).
  * `wgt` is the layer's weight pre-packed by fn2_pack_* layout rules (see DESIGN.md "weights"):
  *   [phase][cout_pad][kpad] elements of in.dtype, k = (tap, channel) with channels padded to a
  *   multiple of 8, kpad a multiple of the k-step; cout_pad a multiple of the block's cout tile (fn2_conv2d_plan). */
@@ -135,13 +138,14 @@ typedef struct {
   fn2_tensor out;      /* out.c = Cout; out.dtype may be FN2_F32 while in is bf16 (flow heads) */
   const void* wgt;
   const float* bias;   /* [Cout] fp32 or NULL */
-  int32_t kind;        /* 0 conv, 1 deconv 4x4 s2 crop 1, 2 stem row-run conv (see fn2_conv2d) */
+  int32_t kind;        /* 0 conv, 1 deconv 4x4 s2 crop 1, 2 stem row-run conv, 3 transpose of a stride-2 conv */
   int32_t kh, kw, stride, pad;
   int32_t act;         /* fn2_act */
   int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */
   int32_t cout_pad;    /* rows per phase in the packed weight */
   int32_t kpad;        /* elements per packed row */
   int32_t wgt_layout;  /* row order of the packed weight: fn2_conv_plan.layout */
+  int32_t accumulate;  /* 1: out += result (fp32 outputs only): gradient accumulation */
   float out_scale;     /* accumulator scale applied before the bias (0 = 1): lets the packer store
                           2^k-scaled weights so that split-fp16 lo parts stay normal fp16 numbers */
   void* workspace;     /* fp32 scratch for split-K partial sums, or NULL (then no split-K) */
@@ -197,6 +201,48 @@ int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2
  * [a(3) | flow_sd(2) | flow_css(2) | |sd| | |css| | |a-warp(b,sd)| | |a-warp(b,css)| | 0...]. */
 int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const float* flow_css,
                      const fn2_tensor* out, int pad, void* stream);
+
+/* ---------------------------------------------------------------- training step (fp32)
+ * What the reference obtains from tf.gradients + tf.train.AdamOptimizer over the FlowNetS loss
+ * (src/net.py:1290-1295, :1386-1392; src/flownet_s/flownet_s.py:122-161; src/utils.py:209-224).
+ * Input gradients of the conv layers are fn2_conv2d launches (kind 0 on rotated weights, kind 3,
+ * kind 0 k4 s2 for the transposed convs) with `accumulate`. */
+
+/* L = weight * sum_pixels ||pred - label||_2 / n added to *loss_accum (device scalar);
+ * dpred = weight / n * (pred - label) / ||pred - label||  (average_endpoint_error, utils.py:209-224). */
+int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float* loss_accum, int n, int h, int w,
+                      float weight, void* stream);
+/* g *= LeakyReLU'(.) evaluated from the layer output y (utils.py:401-405); y, g fp32 channel-slice views. */
+int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, void* stream);
+/* db[c] += sum over pixels of g (db zeroed by the caller). */
+int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream);
+/* dst[i] = map[i] >= 0 ? src[map[i]] : 0: derives the weight layouts of the input-gradient convolutions. */
+int fn2_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, void* stream);
+/* tf.train.AdamOptimizer update of n parameters with g' = grad_scale*g + l2*w (slim l2_regularizer). */
+int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, float l2, float grad_scale, void* stream);
+/* upsample_flowXtoY backward: g = gradient view [n,2h,2w,2] of its output slice, pf its fp32 input [n,h,w,2],
+ * w [4][4][2][2]; dpf (+)= input gradient, dw += filter gradient. */
+int fn2_upsample_flow_bwd(const fn2_tensor* g, const float* pf, const float* w, float* dpf, float* dw,
+                          int accumulate, void* stream);
+/* flow head (3x3 s1 p1, 2 outputs) filter gradient into rows 0,1 of its natural-order packed weight. */
+int fn2_head_bwd_filter(const fn2_tensor* x, const float* g, float* dw, int cin_pad, int kpad, void* stream);
+/* flow head input gradient, ADDED into the view dx: dx[pix][ci] += sum_{tap,co} g[pix-(tap-1)][co] * w[co][tap][ci]. */
+int fn2_head_bwd_data(const float* g, const float* w, const fn2_tensor* dx, int cin_pad, int kpad, void* stream);
+
+/* Filter gradient of one conv layer on the fp32 matrix cores, ADDED into `dw`, which has the layout of the
+ * layer's packed forward weight (fn2_conv_desc.wgt: same cin_pad / cout_pad / kpad / wgt_layout).
+ *   kind 0: conv            dW[co][tap][ci] += sum x[pix*s + tap - pad][ci] * dy[pix][co]
+ *   kind 1: deconv k4 s2    dWt (4-phase packing) += sum x[pix][ci] * dy[2 pix + tap - 1][co]
+ *   kind 2: stem row-run conv (x = the pre-padded buffer, pad = 0, cin_pad = run length) */
+typedef struct {
+  fn2_tensor x;        /* layer input (fp32) */
+  fn2_tensor dy;       /* gradient wrt the layer's pre-activation output (fp32) */
+  float* dw;
+  int32_t kind, kh, kw, stride, pad;
+  int32_t cin_pad, cout_pad, kpad, wgt_layout;
+} fn2_bwdw_desc;
+int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream);
 
 /* ---------------------------------------------------------------- launch-graph helpers (hipGraph) */
 int fn2_capture_begin(void* stream);

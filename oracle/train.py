@@ -1,0 +1,94 @@
+"""Oracle (test infrastructure): FlowNetS loss gradients and the Adam update on CPU.
+
+The gradient of the reference's loss graph (what tf.gradients produces) is obtained by running the same
+graph in torch float64 on the CPU and using autograd; the graph is the one restated in oracle/models.py
+(flownet_s.py:14-161) and tests check this torch forward against that NumPy forward on the same weights.
+PARITY UNPINNED like oracle/nn.py (TensorFlow is not available).  The Adam update restates
+tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v moments; w -= lr_t*m/(sqrt(v)+eps).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+LOSS_WEIGHTS = {6: 0.32, 5: 0.08, 4: 0.02, 3: 0.01, 2: 0.005}
+
+
+def _leaky(x, positive=None):
+    if positive is not None:
+        return torch.where(torch.as_tensor(positive).permute(0, 3, 1, 2), x, 0.1 * x)
+    return 0.55 * x + 0.45 * x.abs()  # utils.py:401-405
+
+
+def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS", l2=0.0, act_grads=None, signs=None):
+    """Returns (loss, {variable name: gradient in the reference layout}, predictions).  l2 > 0 adds the slim
+    regulariser 0.5*l2*|W|^2 of the slim.conv2d weights to the loss (and so l2*W to their gradients).
+    act_grads: optional dict, filled with {layer name: dLoss/d(layer output), NHWC} for debugging.
+    signs: optional {layer name: bool NHWC array, True where the layer output is positive}.  LeakyReLU has a
+    kink at 0; a pre-activation of magnitude ~1e-7 lands on either side depending on fp32 rounding, and the
+    two branches have gradients 1 and 0.1.  Passing the branch the device actually took makes both sides
+    differentiate the same piecewise-linear function (tests bound how many such elements there are)."""
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in weights.items()
+         if k.startswith(scope + "/")}
+
+    def conv(x, name, stride=1, pad=1, act=True):
+        w = P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1)
+        y = F.conv2d(x, w, P[f"{scope}/{name}/biases"], stride=stride, padding=pad)
+        if act_grads is not None:
+            acts[name + "/pre"] = y
+        y = _leaky(y, None if signs is None else signs.get(name)) if act else y
+        if act_grads is not None:
+            y.retain_grad()
+            acts[name] = y
+        return y
+
+    def deconv(x, name, act=True):
+        w = P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1)  # [ky,kx,o,i] -> [i,o,ky,kx]
+        y = F.conv_transpose2d(x, w, stride=2, padding=1)
+        if act_grads is not None:
+            acts[name + "/pre"] = y
+        return _leaky(y, None if signs is None else signs.get(name)) if act else y
+
+    acts = {}
+    a = torch.tensor(np.asarray(input_a, np.float64)).permute(0, 3, 1, 2)
+    b = torch.tensor(np.asarray(input_b, np.float64)).permute(0, 3, 1, 2)
+    x = torch.cat([a, b], 1)
+    c1 = conv(x, "conv1", 2, 3)
+    c2 = conv(c1, "conv2", 2, 2)
+    c3_1 = conv(conv(c2, "conv3", 2, 2), "conv3_1")
+    c4_1 = conv(conv(c3_1, "conv4", 2), "conv4_1")
+    c5_1 = conv(conv(c4_1, "conv5", 2), "conv5_1")
+    c6_1 = conv(conv(c5_1, "conv6", 2), "conv6_1")
+    preds = {6: conv(c6_1, "predict_flow6", act=False)}
+    cur = c6_1
+    for lvl, skip in zip((5, 4, 3, 2), (c5_1, c4_1, c3_1, c2)):
+        cur = torch.cat([skip, deconv(cur, f"deconv{lvl}"),
+                         deconv(preds[lvl + 1], f"upsample_flow{lvl + 1}to{lvl}", act=False)], 1)
+        preds[lvl] = conv(cur, f"predict_flow{lvl}", act=False)
+    n = a.shape[0]
+    gt = np.asarray(gt_flow, np.float32) * np.float32(0.05)
+    loss = 0.0
+    for lvl, wgt in LOSS_WEIGHTS.items():
+        p = preds[lvl]
+        label = torch.tensor(ops.downsample(gt, (p.shape[2], p.shape[3])).astype(np.float64)).permute(0, 3, 1, 2)
+        loss = loss + wgt * torch.sqrt(((p - label) ** 2).sum(1)).sum() / n
+    loss = loss / 5.0  # compute_weighted_loss, SUM_BY_NONZERO_WEIGHTS over the five scalars
+    if l2 > 0:
+        for k, v in P.items():
+            if k.endswith("/weights") and "deconv" not in k and "upsample_flow" not in k:
+                loss = loss + 0.5 * l2 * (v ** 2).sum()
+    loss.backward()
+    grads = {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}
+    if act_grads is not None:
+        act_grads.update({k: v.grad.permute(0, 2, 3, 1).numpy() for k, v in acts.items() if not k.endswith("/pre")})
+        act_grads.update({k + "/value": v.detach().permute(0, 2, 3, 1).numpy() for k, v in acts.items()})
+    out = {f"predict_flow{l}": p.detach().permute(0, 2, 3, 1).numpy() for l, p in preds.items()}
+    return float(loss.detach()), grads, out
+
+
+def adam_update(w, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    lr_t = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    return w - lr_t * m / (np.sqrt(v) + eps), m, v

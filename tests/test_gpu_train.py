@@ -1,0 +1,122 @@
+"""FlowNetS training step (BASELINE config 4 semantics at reduced size): HIP loss / gradients / Adam against
+the CPU oracle (torch float64 autograd of the restated graph + NumPy Adam)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as refm
+from oracle import train as reft
+
+def data(n, h, w, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.random((n, h, w, 3), dtype=np.float32)
+    b = np.clip(np.roll(a, (2, -3), (1, 2)) + rng.uniform(-0.02, 0.02, a.shape), 0, 1).astype(np.float32)
+    gt = np.clip(rng.standard_normal((n, h, w, 2)) * 5, -40, 40).astype(np.float32)
+    return a, b, gt
+
+
+def device_signs(tr):
+    """Branch of every LeakyReLU as the device took it (see oracle.train: the kink at 0)."""
+    out = {}
+    for rec in tr.eng.layers:
+        if rec["kind"] != "upflow" and rec["act"]:
+            buf, c0, c = rec["dst"]
+            out[rec["name"]] = (buf[..., c0:c0 + c] > 0).cpu().numpy()
+    return out
+
+
+def check_kink_elements(signs, pre):
+    """Device and float64 oracle may only disagree on the LeakyReLU branch where the pre-activation is ~0."""
+    flips = 0
+    for name, sg in signs.items():
+        p = pre[name + "/pre/value"]
+        bad = sg != (p > 0)
+        assert np.abs(p[bad]).max(initial=0.0) < 1e-4, name
+        flips += int(bad.sum())
+    return flips
+
+
+def packed_grad(rec, g):
+    """Oracle gradient (reference layout) -> the packed layout of the layer's weight."""
+    from src import weights as W
+    if rec["kind"] == 1:
+        return W.pack_deconv(g.astype(np.float32), rec["tile"], rec["kstep"], rec["cin_pad"], rec["layout"])[0]
+    if rec["kind"] == 2:
+        return W.pack_stem(g.astype(np.float32), rec["cs"], rec["cin_pad"], rec["tile"], rec["layout"])[0]
+    return W.pack_conv(g.astype(np.float32), rec["tile"], rec["kstep"], rec["cin_pad"], rec["layout"])[0]
+
+
+def test_oracle_torch_forward_equals_numpy_forward():
+    from src import weights as W
+    wts = W.init_weights("FlowNetS", 5)
+    a, b, gt = data(1, 128, 128, 0)
+    _, _, preds = reft.flownet_s_loss_and_grads(wts, a, b, gt)
+    want = refm.flownet_s(wts, {"input_a": a, "input_b": b})
+    for k in preds:
+        np.testing.assert_allclose(preds[k], want[k], rtol=1e-9, atol=1e-11)
+    loss_np, _ = refm.multiscale_loss(gt, want, None)
+    loss_t, _, _ = reft.flownet_s_loss_and_grads(wts, a, b, gt)
+    assert abs(loss_np - loss_t) < 1e-9 * max(1.0, abs(loss_np))
+
+
+@pytest.mark.gpu
+def test_flownet_s_gradients_match_oracle():
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetS", 5)
+    a, b, gt = data(2, 128, 192, 1)
+    tr = FlowNetSTrainer(wts, 2, 128, 192)
+    loss = float(tr.forward_backward(a, b, gt).item())
+    signs, pre = device_signs(tr), {}
+    want_loss, grads, _ = reft.flownet_s_loss_and_grads(wts, a, b, gt, signs=signs, act_grads=pre)
+    assert abs(loss - want_loss) < 2e-5 * abs(want_loss)
+    print("LeakyReLU branch disagreements at |pre-activation| < 1e-4: %d" % check_kink_elements(signs, pre))
+    worst = 0.0
+    for rec in tr.eng.layers:
+        name = f"{rec['scope']}/{rec['name']}"
+        got = rec["dw"].cpu().numpy()
+        if rec["kind"] == "upflow":
+            want = grads[name + "/weights"].astype(np.float32).reshape(-1)
+        else:
+            want = packed_grad(rec, grads[name + "/weights"]).reshape(-1)
+        scale = np.abs(want).max() + 1e-12
+        err = np.abs(got - want).max() / scale
+        berr = 0.0
+        if rec.get("b") is not None:
+            gb, wb = rec["db"].cpu().numpy(), grads[name + "/biases"]
+            berr = np.abs(gb - wb).max() / (np.abs(wb).max() + 1e-12)
+        print("  %-28s filter %.2e  bias %.2e" % (name, err, berr))
+        worst = max(worst, err, berr)
+    print("max relative gradient error over all layers: %.2e" % worst)
+    assert worst < 2e-5
+
+
+@pytest.mark.gpu
+def test_adam_steps_match_oracle():
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetS", 6)
+    a, b, gt = data(1, 128, 128, 2)
+    tr = FlowNetSTrainer(wts, 1, 128, 128)
+    cur = {k: np.asarray(v, np.float64) for k, v in wts.items()}
+    mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in cur.items()}
+    l2 = tr.schedule["l2_regularization"]
+    for step in (1, 2):
+        tr.forward_backward(a, b, gt)
+        signs = device_signs(tr)
+        tr.apply_gradients()
+        _, grads, _ = reft.flownet_s_loss_and_grads(cur, a, b, gt, l2=l2, signs=signs)
+        for k in cur:
+            g = grads[k]
+            cur[k], m, v = reft.adam_update(cur[k], g, mom[k][0], mom[k][1], step)
+            mom[k] = (m, v)
+    for rec in tr.eng.layers:
+        name = f"{rec['scope']}/{rec['name']}/weights"
+        got = rec["w"].cpu().numpy().reshape(-1)
+        want = cur[name].astype(np.float32)
+        want = want.reshape(-1) if rec["kind"] == "upflow" else packed_grad(rec, want).reshape(-1)
+        # two Adam steps move every weight by ~2e-4; compare the MOVEMENT, not the value
+        w0 = np.asarray(wts[name], np.float32)
+        w0 = w0.reshape(-1) if rec["kind"] == "upflow" else packed_grad(rec, w0).reshape(-1)
+        move_got, move_want = got - w0, want - w0
+        assert np.abs(move_got - move_want).max() < 0.05 * np.abs(move_want).max(), name
