@@ -50,27 +50,62 @@ __global__ void __launch_bounds__(256) epe_loss_grad_kernel(const float* __restr
   if (threadIdx.x == 0) atomicAdd(loss_accum, (s[0] + s[1] + s[2] + s[3]) * scale);
 }
 
-// LeakyReLU backward in place on a channel slice: g *= d/dx (0.55 x + 0.45 |x|) evaluated from the
-// layer OUTPUT y (same sign as x): 1 for y > 0, 0.1 for y < 0, 0.55 at 0 (tf.abs' = sign).
-__global__ void __launch_bounds__(256) leaky_bwd_kernel(const float* __restrict__ y, float* __restrict__ g, long npix,
-                                                        int c, int y_cs, int y_c0, int g_cs, int g_c0) {
-  const int c4 = c >> 2;
-  const long total = npix * c4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long pix = i / c4;
-    const int ch = (int)(i - pix * c4) * 4;
-    const float4 yv = *reinterpret_cast<const float4*>(y + pix * y_cs + y_c0 + ch);
-    float4* gp = reinterpret_cast<float4*>(g + pix * g_cs + g_c0 + ch);
-    float4 gv = *gp;
-    gv.x *= yv.x > 0.f ? 1.f : (yv.x < 0.f ? 0.1f : 0.55f);
-    gv.y *= yv.y > 0.f ? 1.f : (yv.y < 0.f ? 0.1f : 0.55f);
-    gv.z *= yv.z > 0.f ? 1.f : (yv.z < 0.f ? 0.1f : 0.55f);
-    gv.w *= yv.w > 0.f ? 1.f : (yv.w < 0.f ? 0.1f : 0.55f);
-    *gp = gv;
+// LeakyReLU backward in place on a channel slice, fused with the bias gradient of the same layer:
+//   g *= d/dx (0.55 x + 0.45 |x|) evaluated from the layer OUTPUT y (same sign as x): 1 for y > 0, 0.1 for
+//   y < 0, 0.55 at 0 (tf.abs' = sign);   db[c] += sum over pixels of the new g[pixel][c].
+// ACT = false: bias gradient only (g is not written).  db == nullptr: activation only.
+// Block = a pixel range x GPB float4 channel groups (GPB a power of two <= 256, threads beyond c/4 idle);
+// consecutive threads read consecutive 16-byte groups of a pixel, the 256/GPB thread rows stride the pixels.
+// HBM-bound: reads y and g once, writes g once.
+template <bool ACT>
+__global__ void __launch_bounds__(256) act_bias_bwd_kernel(const float* __restrict__ y, float* __restrict__ g,
+                                                           float* __restrict__ db, long npix, int c, int y_cs, int y_c0,
+                                                           int g_cs, int g_c0, int gpb_log2) {
+  const int gpb = 1 << gpb_log2, rows = 256 >> gpb_log2;
+  const int tc = threadIdx.x & (gpb - 1), tr = threadIdx.x >> gpb_log2;
+  const int ch = (blockIdx.x * gpb + tc) * 4;
+  const long per = (npix + gridDim.y - 1) / gridDim.y;
+  const long p0 = (long)blockIdx.y * per, p1 = min(npix, p0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ch < c)
+    for (long pix = p0 + tr; pix < p1; pix += rows) {
+      float4* gp = reinterpret_cast<float4*>(g + pix * g_cs + g_c0 + ch);
+      float4 gv = *gp;
+      if constexpr (ACT) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + pix * y_cs + y_c0 + ch);
+        gv.x *= yv.x > 0.f ? 1.f : (yv.x < 0.f ? 0.1f : 0.55f);
+        gv.y *= yv.y > 0.f ? 1.f : (yv.y < 0.f ? 0.1f : 0.55f);
+        gv.z *= yv.z > 0.f ? 1.f : (yv.z < 0.f ? 0.1f : 0.55f);
+        gv.w *= yv.w > 0.f ? 1.f : (yv.w < 0.f ? 0.1f : 0.55f);
+        *gp = gv;
+      }
+      acc.x += gv.x; acc.y += gv.y; acc.z += gv.z; acc.w += gv.w;
+    }
+  if (db == nullptr) return;
+  __shared__ float4 s[256];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  if (tr == 0 && ch < c) {
+    for (int r = 1; r < rows; ++r) {
+      const float4 t = s[r * gpb + tc];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    atomicAdd(db + ch, acc.x); atomicAdd(db + ch + 1, acc.y); atomicAdd(db + ch + 2, acc.z); atomicAdd(db + ch + 3, acc.w);
   }
 }
 
-// bias gradient: db[c] += sum over pixels of g[pixel][c]   (block = 64 channels x a pixel range)
+// bias gradient of a dense 2-channel tensor (the flow heads): db[0..1] += sum of g over pixels.
+__global__ void __launch_bounds__(256) bias_grad2_kernel(const float* __restrict__ g, float* __restrict__ db, long npix) {
+  float a0 = 0.f, a1 = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float2 v = *reinterpret_cast<const float2*>(g + 2 * i);
+    a0 += v.x; a1 += v.y;
+  }
+  a0 = wave_sum_t(a0); a1 = wave_sum_t(a1);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(db, a0); atomicAdd(db + 1, a1); }
+}
+
+// generic fallback (channel count not a multiple of 4): block = 64 channels x a pixel range
 __global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ g, float* __restrict__ db, long npix,
                                                         int c, int g_cs, int g_c0) {
   const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -160,36 +195,67 @@ __global__ void __launch_bounds__(256) upsample_flow_bwd_kernel(const float* __r
   if (threadIdx.x < 64) atomicAdd(dw + threadIdx.x, sdw[threadIdx.x]);
 }
 
-// Flow-head filter gradient (3x3, stride 1, pad 1, Cout = 2): dw[co][tap*cin_pad + ci] += sum_pix x[pix+tap][ci]*g[pix][co].
-// block = (tap, 64-channel chunk, pixel range): lane = channel, the 4 waves stride the pixels.
+// Flow-head filter gradient (3x3, stride 1, pad 1, Cout = 2):
+//   dw[co][tap*cin_pad + ci] += sum_{iy,ix} x[iy][ix][ci] * g[iy - ky + 1][ix - kx + 1][co]
+// x is read ONCE: a thread owns 4 channels (one float4 per pixel) and all 9 taps x 2 outputs = 72 accumulators;
+// the 18 g values of a pixel are wave-uniform per 16-lane group (L1 broadcast).  Block = 64 channels x a pixel
+// range; lane = (16 channel groups) x (4 pixel lanes), 4 waves stride the pixels further.  HBM-bound on x.
 __global__ void __launch_bounds__(256) head_bwd_filter_kernel(const float* __restrict__ x, int x_cs, int x_c0, int cin,
                                                               const float* __restrict__ g, float* __restrict__ dw,
                                                               int cin_pad, int kpad, int N, int H, int W) {
-  const int tap = blockIdx.y, ky = tap / 3, kx = tap - ky * 3;
-  const int ci = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sub = threadIdx.x >> 6;
+  const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;  // 16 pixel lanes per block
+  const int ci = blockIdx.x * 64 + cg * 4;
   const long npix = (long)N * H * W;
-  const long per = (npix + gridDim.z - 1) / gridDim.z;
-  const long p0 = (long)blockIdx.z * per, p1 = min(npix, p0 + per);
-  float a0 = 0.f, a1 = 0.f;
+  const long per = (npix + gridDim.y - 1) / gridDim.y;
+  const long p0 = (long)blockIdx.y * per, p1 = min(npix, p0 + per);
+  float acc[9][2][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[t][o][q] = 0.f;
   if (ci < cin)
-    for (long pix = p0 + sub; pix < p1; pix += 4) {
-      const int px = (int)(pix % W), py = (int)((pix / W) % H);
-      const int iy = py + ky - 1, ix = px + kx - 1;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const float xv = x[(pix + (long)(ky - 1) * W + (kx - 1)) * x_cs + x_c0 + ci];
-      const float2 gv = *reinterpret_cast<const float2*>(g + pix * 2);
-      a0 += xv * gv.x;
-      a1 += xv * gv.y;
+    for (long pix = p0 + pl; pix < p1; pix += 16) {
+      const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+      const float4 xv = *reinterpret_cast<const float4*>(x + pix * x_cs + x_c0 + ci);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int oy = iy - ky + 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ox = ix - kx + 1;
+          float2 gv = make_float2(0.f, 0.f);
+          if (oy >= 0 && oy < H && ox >= 0 && ox < W)
+            gv = *reinterpret_cast<const float2*>(g + (pix + (long)(1 - ky) * W + (1 - kx)) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[ky * 3 + kx][0][q] += xs[q] * gv.x;
+            acc[ky * 3 + kx][1][q] += xs[q] * gv.y;
+          }
+        }
+      }
     }
-  __shared__ float s[2][4][64];
-  s[0][sub][threadIdx.x & 63] = a0;
-  s[1][sub][threadIdx.x & 63] = a1;
+  // reduce the 4 pixel lanes of a wave by shuffles, the 4 waves through LDS
+  __shared__ float s[4][16][72];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = acc[t][o][q];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if ((threadIdx.x & 63) < 16) s[wave][cg][(t * 2 + o) * 4 + q] = v;
+      }
   __syncthreads();
-  if (sub == 0 && ci < cin) {
-    const int l = threadIdx.x;
-    atomicAdd(dw + (size_t)tap * cin_pad + ci, s[0][0][l] + s[0][1][l] + s[0][2][l] + s[0][3][l]);
-    atomicAdd(dw + (size_t)kpad + (size_t)tap * cin_pad + ci, s[1][0][l] + s[1][1][l] + s[1][2][l] + s[1][3][l]);
+  for (int e = threadIdx.x; e < 16 * 72; e += 256) {
+    const int g16 = e / 72, r = e - g16 * 72, t = r >> 3, o = (r >> 2) & 1, q = r & 3;
+    const int c = blockIdx.x * 64 + g16 * 4 + q;
+    if (c < cin) atomicAdd(dw + (size_t)o * kpad + (size_t)t * cin_pad + c, s[0][g16][r] + s[1][g16][r] + s[2][g16][r] + s[3][g16][r]);
   }
 }
 
@@ -257,6 +323,9 @@ __device__ __forceinline__ int perm32(int r) {  // packed row of output channel 
   return g + (rr & 3) + 8 * (rr >> 2) + 4 * h;
 }
 
+// SWAP: the MFMA computes D^T (lane = i, registers = j) so that the atomics of a wave instruction are
+// contiguous when i is the fastest index of dw (the transposed convolutions, stride_i == 1).
+template <bool SWAP>
 __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PK = 32;  // pixels per stage
@@ -326,27 +395,45 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
     for (int kk = 0; kk < PK; kk += 2) {
       const int row = (kk + fk) * 128;
       const float a0 = Dn[row], a1 = Dn[row + 32], b0 = Sm[row], b1 = Sm[row + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if constexpr (SWAP) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+      } else {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  // D layout (32x32): col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // D layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); (row, col) = (i, j), or (j, i) if SWAP
   float* base = p.dw + p.tap_base[tap];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
-      const int j = j0 + wj * 64 + tj * 32 + fr;
-      if (j >= p.Cj) continue;
-      const long oj = (long)(p.perm_j ? perm32(j) : j) * p.stride_j;
+      if constexpr (SWAP) {
+        const int i = i0 + wi * 64 + ti * 32 + fr;
+        if (i >= p.Ci) continue;
+        const long oi = (long)(p.perm_i ? perm32(i) : i) * p.stride_i;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int i = i0 + wi * 64 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
-        if (i < p.Ci) atomicAdd(base + (long)(p.perm_i ? perm32(i) : i) * p.stride_i + oj, acc[ti][tj][q]);
+        for (int q = 0; q < 16; ++q) {
+          const int j = j0 + wj * 64 + tj * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+          if (j < p.Cj) atomicAdd(base + (long)(p.perm_j ? perm32(j) : j) * p.stride_j + oi, acc[ti][tj][q]);
+        }
+      } else {
+        const int j = j0 + wj * 64 + tj * 32 + fr;
+        if (j >= p.Cj) continue;
+        const long oj = (long)(p.perm_j ? perm32(j) : j) * p.stride_j;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = i0 + wi * 64 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+          if (i < p.Ci) atomicAdd(base + (long)(p.perm_i ? perm32(i) : i) * p.stride_i + oj, acc[ti][tj][q]);
+        }
       }
     }
 #endif
@@ -369,15 +456,25 @@ int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float
   return FN2_OK;
 }
 
-int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, void* stream) {
+static int gpb_log2_for(int c4) {
+  int l = 0;
+  while ((1 << l) < c4 && l < 8) ++l;
+  return l;
+}
+
+int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* stream) {
   FN2_REQUIRE(y && g && y->data && g->data, "leaky_bwd: null tensor");
   FN2_REQUIRE(y->dtype == FN2_F32 && g->dtype == FN2_F32, "leaky_bwd: fp32 only");
   FN2_REQUIRE(y->n == g->n && y->h == g->h && y->w == g->w && y->c == g->c, "leaky_bwd: shape mismatch");
   FN2_REQUIRE(y->c % 4 == 0 && y->cs % 4 == 0 && y->c0 % 4 == 0 && g->cs % 4 == 0 && g->c0 % 4 == 0,
               "leaky_bwd: channel slice must be 4-aligned");
   const long npix = (long)y->n * y->h * y->w;
-  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(npix * (y->c / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)y->data, (float*)g->data, npix, y->c, y->cs, y->c0, g->cs, g->c0);
+  const int l2 = gpb_log2_for(y->c / 4);
+  long splits = (npix + 63) / 64;
+  if (splits > 2048) splits = 2048;
+  hipLaunchKernelGGL(act_bias_bwd_kernel<true>, dim3((y->c / 4 + (1 << l2) - 1) >> l2, (int)splits), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)y->data, (float*)g->data, db, npix, y->c, y->cs, y->c0, g->cs,
+                     g->c0, l2);
   FN2_CHECK_LAUNCH("leaky_bwd");
   return FN2_OK;
 }
@@ -386,10 +483,21 @@ int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream) {
   FN2_REQUIRE(g && g->data && db, "bias_grad: null pointer");
   FN2_REQUIRE(g->dtype == FN2_F32, "bias_grad: fp32 only");
   const long npix = (long)g->n * g->h * g->w;
-  int splits = (int)((npix + 4095) / 4096);
-  if (splits > 256) splits = 256;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((g->c + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)g->data, db, npix, g->c, g->cs, g->c0);
+  hipStream_t st = (hipStream_t)stream;
+  if (g->c == 2 && g->cs == 2 && g->c0 == 0) {
+    hipLaunchKernelGGL(bias_grad2_kernel, dim3(grid_for(npix, 1024)), dim3(256), 0, st, (const float*)g->data, db, npix);
+  } else if (g->c % 4 == 0 && g->cs % 4 == 0 && g->c0 % 4 == 0) {
+    const int l2 = gpb_log2_for(g->c / 4);
+    long splits = (npix + 63) / 64;
+    if (splits > 2048) splits = 2048;
+    hipLaunchKernelGGL(act_bias_bwd_kernel<false>, dim3((g->c / 4 + (1 << l2) - 1) >> l2, (int)splits), dim3(256), 0, st,
+                       (const float*)nullptr, (float*)g->data, db, npix, g->c, 0, 0, g->cs, g->c0, l2);
+  } else {
+    int splits = (int)((npix + 4095) / 4096);
+    if (splits > 256) splits = 256;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((g->c + 63) / 64, splits), dim3(256), 0, st, (const float*)g->data, db,
+                       npix, g->c, g->cs, g->c0);
+  }
   FN2_CHECK_LAUNCH("bias_grad");
   return FN2_OK;
 }
@@ -427,10 +535,11 @@ int fn2_upsample_flow_bwd(const fn2_tensor* g, const float* pf, const float* w, 
 int fn2_head_bwd_filter(const fn2_tensor* x, const float* g, float* dw, int cin_pad, int kpad, void* stream) {
   FN2_REQUIRE(x && x->data && g && dw, "head_bwd_filter: null pointer");
   FN2_REQUIRE(x->dtype == FN2_F32 && cin_pad >= x->c && kpad >= 9 * cin_pad, "head_bwd_filter: bad layout");
+  FN2_REQUIRE(x->cs % 4 == 0 && x->c0 % 4 == 0 && (x->c + 3) / 4 * 4 <= x->cs - x->c0, "head_bwd_filter: x view must be 16-byte aligned and padded to 4 channels");
   const long npix = (long)x->n * x->h * x->w;
-  int splits = (int)((npix + 2047) / 2048);
-  if (splits > 128) splits = 128;
-  hipLaunchKernelGGL(head_bwd_filter_kernel, dim3((x->c + 63) / 64, 9, splits), dim3(256), 0, (hipStream_t)stream,
+  int splits = (int)((npix + 511) / 512);
+  if (splits > 512) splits = 512;
+  hipLaunchKernelGGL(head_bwd_filter_kernel, dim3((x->c + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream,
                      (const float*)x->data, x->cs, x->c0, x->c, g, dw, cin_pad, kpad, x->n, x->h, x->w);
   FN2_CHECK_LAUNCH("head_bwd_filter");
   return FN2_OK;
@@ -465,8 +574,14 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
     dn = &d->dy; sm = &d->x;   // D[i = co][j = ci]
     a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.stride_i = d->kpad; a.stride_j = 1; a.perm_i = d->wgt_layout == 1; a.perm_j = 0;
-    for (int t = 0; t < d->kh * d->kw; ++t)
-      a.tap_base[t] = d->kind == 2 ? (t / d->kw) * d->cin_pad + (t % d->kw) * d->x.cs : t * d->cin_pad;
+    if (d->kind == 2) {
+      // row-run stem: the kw taps x cs channels of a kernel row are ONE contiguous run of the pre-padded input,
+      // so a kernel row is a single "tap" of kw*cs sampled channels (same trick as the forward kind-2 kernel)
+      a.KW = 1;
+      for (int t = 0; t < d->kh; ++t) a.tap_base[t] = t * d->cin_pad;
+    } else {
+      for (int t = 0; t < d->kh * d->kw; ++t) a.tap_base[t] = t * d->cin_pad;
+    }
   } else {
     FN2_REQUIRE(d->kh == 4 && d->kw == 4 && d->stride == 2, "bwd_filter: deconv is k4 s2 crop 1");
     FN2_REQUIRE(d->dy.h == 2 * d->x.h && d->dy.w == 2 * d->x.w, "bwd_filter: deconv dy must be 2H x 2W");
@@ -481,7 +596,7 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   }
   a.dn = (const float*)dn->data; a.sm = (const float*)sm->data; a.dw = d->dw;
   a.N = dn->n; a.DH = dn->h; a.DW_ = dn->w; a.dn_cs = dn->cs; a.dn_c0 = dn->c0; a.Ci = dn->c;
-  a.SH = sm->h; a.SW = sm->w; a.sm_cs = sm->cs; a.sm_c0 = sm->c0; a.Cj = sm->c;
+  a.SH = sm->h; a.SW = sm->w; a.sm_cs = sm->cs; a.sm_c0 = sm->c0; a.Cj = d->kind == 2 ? d->kw * sm->cs : sm->c;
   const long dnb = (long)dn->n * dn->h * dn->w * dn->cs * 4, smb = (long)sm->n * sm->h * sm->w * sm->cs * 4;
   FN2_REQUIRE(dnb < (1L << 31) && smb < (1L << 31), "bwd_filter: tensors >= 2 GiB are not addressable");
   a.dn_bytes = (int)dnb; a.sm_bytes = (int)smb;
@@ -496,7 +611,10 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   if (splits < 1) splits = 1;
   a.pix_per_split = (((a.P + splits - 1) / splits) + 31) / 32 * 32;
   splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
-  hipLaunchKernelGGL(bwd_filter_kernel, dim3(it, jt * taps, splits), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->kind == 1)
+    hipLaunchKernelGGL(bwd_filter_kernel<true>, dim3(it, jt * taps, splits), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(bwd_filter_kernel<false>, dim3(it, jt * taps, splits), dim3(256), 0, (hipStream_t)stream, a);
   FN2_CHECK_LAUNCH("bwd_filter");
   return FN2_OK;
 }

@@ -1,7 +1,8 @@
 """Multi-GPU inference: image pairs are independent, so a batch shards across ranks (one
 process per GPU) with NO collective on the data path; the only communication is the optional
-gather of finished flow fields on rank 0.  The reference is single-GPU (SURVEY.md section 2:
-no distributed code), so this module has no counterpart there.
+gather of finished flow fields on rank 0.  Multi-GPU training: one all-reduce of the flat
+gradient arena per step (allreduce_gradients).  The reference is single-GPU (SURVEY.md
+section 2: no distributed code), so this module has no counterpart there.
 
 torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
@@ -33,3 +34,18 @@ def gather_flows(local_flows, n_total, dst=0):
     if rank != dst:
         return None
     return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def allreduce_gradients(flat):
+    """SUM the flat fp32 gradient arena over all ranks, in place (one collective per step: the arena is a
+    single contiguous buffer, ~155 MB for FlowNetS, so the ring runs at xGMI link bandwidth rather than
+    launch latency).  The 1/world mean is folded into the Adam kernel's grad_scale.  Returns world size."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    if flat.is_cuda and dist.get_backend() == "gloo":  # CPU-rendezvous tests of the GPU trainer
+        host = flat.cpu()
+        dist.all_reduce(host)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat)
+    return dist.get_world_size()

@@ -51,11 +51,11 @@ def _index_hwio(rec):
 
 
 class FlowNetSTrainer:
-    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8, world_size=1):
+    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8):
         self.eng = Engine("FlowNetS", weights, batch, height, width, "f32")
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
-        self.schedule, self.eps, self.world = schedule, eps, world_size
+        self.schedule, self.eps = schedule, eps
         self.step_count = 0
         self.keep = []
         self.gt = torch.zeros((batch, height, width, 2), dtype=torch.float32, device=self.dev)
@@ -153,6 +153,11 @@ class FlowNetSTrainer:
         d.out_scale = 1.0
         self.keep += [d, wb, gmap]
         self.eng.conv_descs.append(d)  # shares the split-K workspace
+        if plan.layout == 1:
+            d.kernel_name = "conv_igemm2_kernel<float, float, %s>" % ("2, 2" if plan.cout_tile == 128 else "1, 4")
+        else:
+            d.kernel_name = "conv_igemm_kernel<float, float, %s>" % {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4",
+                                                                      16: "1, 1, 4"}[plan.cout_tile]
         return d
 
     def _plan_conv(self, rec):
@@ -162,10 +167,11 @@ class FlowNetSTrainer:
         ops = []
         vy, vg = self._view(dbuf, dc, dc0), self._view(gy, dc, dc0)
         self.keep += [vy, vg]
+        db = _hip.ptr(rec["db"]) if rec.get("b") is not None else None
         if rec["act"]:
-            ops.append((self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg))))
-        if rec.get("b") is not None:
-            ops.append((self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"]))))
+            ops.append((self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg), db)))  # + bias gradient, same pass
+        elif db is not None:
+            ops.append((self.lib.fn2_bias_grad, (C.byref(vg), db)))
         bd = _hip.Fn2BwdwDesc()
         bd.x = self._view(sbuf, sc, sc0)
         bd.dy = vg
@@ -212,6 +218,20 @@ class FlowNetSTrainer:
         ops = [(self.lib.fn2_upsample_flow_bwd, (C.byref(vg), _hip.ptr(pf), _hip.ptr(rec["w"]), _hip.ptr(self._gbuf(pf)),
                                                  _hip.ptr(rec["dw"]), 1))]
         self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
+
+    def backward_launches(self):
+        """[(name, fn, args, device kernel, algorithmic flop)] of one backward pass, for per-launch timing."""
+        flops = dict(self.eng.layer_flops)
+        out = []
+        for name, ops in self.bwd_ops:
+            for fn, args in ops:
+                fl, kern = 0.0, fn.__name__.replace("fn2_", "") + "_kernel"
+                if fn is self.lib.fn2_conv2d:
+                    fl, kern = flops.get(name, 0.0), args[0]._obj.kernel_name
+                elif fn is self.lib.fn2_conv2d_bwd_filter:
+                    fl, kern = flops.get(name, 0.0), "bwd_filter_kernel"
+                out.append(("bwd " + name, fn, args, kern, fl))
+        return out
 
     # ------------------------------------------------------------------ step
     def refresh_backward_weights(self):
@@ -262,10 +282,11 @@ class FlowNetSTrainer:
         l2 = self.schedule["l2_regularization"]
         return float(sum(0.5 * l2 * float((p["w"].double() ** 2).sum()) for p in self.params if p["reg"]))
 
-    def apply_gradients(self):
-        import torch.distributed as dist
-        if self.world > 1:
-            dist.all_reduce(self.grad_arena)  # RCCL sum over xGMI; the mean is folded into Adam's grad_scale
+    def apply_gradients(self, reduced_world=None):
+        """All-reduce (unless the caller already did: reduced_world = number of ranks summed) + Adam."""
+        from .dist import allreduce_gradients
+        # RCCL sum over xGMI; the mean is folded into Adam's grad_scale
+        world = reduced_world if reduced_world is not None else allreduce_gradients(self.grad_arena)
         self.step_count += 1
         lr = self.learning_rate(self.step_count - 1)
         b1, b2 = self.schedule["momentum"], self.schedule["momentum2"]
@@ -274,7 +295,7 @@ class FlowNetSTrainer:
         for p in self.params:
             _hip.check(self.lib.fn2_adam_step(_hip.ptr(p["w"]), _hip.ptr(p["m"]), _hip.ptr(p["v"]), _hip.ptr(p["g"]),
                                               p["n"], lr, b1, b2, self.eps, self.step_count,
-                                              l2 if p["reg"] else 0.0, 1.0 / self.world, s))
+                                              l2 if p["reg"] else 0.0, 1.0 / world, s))
         self.refresh_backward_weights()
 
     def train_step(self, input_a, input_b, gt_flow):

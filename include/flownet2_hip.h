@@ -212,8 +212,9 @@ int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const
  * dpred = weight / n * (pred - label) / ||pred - label||  (average_endpoint_error, utils.py:209-224). */
 int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float* loss_accum, int n, int h, int w,
                       float weight, void* stream);
-/* g *= LeakyReLU'(.) evaluated from the layer output y (utils.py:401-405); y, g fp32 channel-slice views. */
-int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, void* stream);
+/* g *= LeakyReLU'(.) evaluated from the layer output y (utils.py:401-405); y, g fp32 channel-slice views.
+ * db != NULL: the bias gradient of the same layer in the same pass, db[c] += sum over pixels of the new g. */
+int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* stream);
 /* db[c] += sum over pixels of g (db zeroed by the caller). */
 int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream);
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0: derives the weight layouts of the input-gradient convolutions. */

@@ -53,3 +53,31 @@ def test_two_rank_shard_and_gather(tmp_path, n_total):
     got = np.load(out)
     assert got.shape == (n_total, 4, 6, 2)
     assert np.array_equal(got[:, 0, 0, 0], np.arange(n_total, dtype=np.float32))
+
+
+def _grad_worker(rank, world, port, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "flownet2-tf_amd"))
+    from src.dist import allreduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)  # stand-in for the gradient arena of this rank
+    assert allreduce_gradients(flat) == world
+    if rank == 0:
+        np.save(out_path, flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    out = str(tmp_path / "g.npy")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.array_equal(np.load(out), np.arange(1000, dtype=np.float32) * 3)
+
+
+def test_allreduce_without_process_group_is_identity():
+    sys.path.insert(0, os.path.join(ROOT, "flownet2-tf_amd"))
+    from src.dist import allreduce_gradients
+    flat = torch.ones(8)
+    assert allreduce_gradients(flat) == 1 and torch.equal(flat, torch.ones(8))

@@ -1,5 +1,8 @@
 """FlowNetS training step (BASELINE config 4 semantics at reduced size): HIP loss / gradients / Adam against
 the CPU oracle (torch float64 autograd of the restated graph + NumPy Adam)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -120,3 +123,52 @@ def test_adam_steps_match_oracle():
         w0 = w0.reshape(-1) if rec["kind"] == "upflow" else packed_grad(rec, w0).reshape(-1)
         move_got, move_want = got - w0, want - w0
         assert np.abs(move_got - move_want).max() < 0.05 * np.abs(move_want).max(), name
+
+
+def _dp_worker(rank, world, port, out_path):
+    """One data-parallel rank on the shared test GPU (gloo rendezvous: RCCL needs one device per rank)."""
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "flownet2-tf_amd")]
+    from src import weights as W
+    from src.dist import allreduce_gradients, shard_range
+    from src.trainer import FlowNetSTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b, gt = data(2, 128, 128, 3)
+    lo, hi = shard_range(2, rank, world)
+    tr = FlowNetSTrainer(W.init_weights("FlowNetS", 7), hi - lo, 128, 128)
+    tr.forward_backward(a[lo:hi], b[lo:hi], gt[lo:hi])
+    n = allreduce_gradients(tr.grad_arena)
+    grads = (tr.grad_arena / n).cpu().numpy()
+    tr.apply_gradients(reduced_world=n)
+    tr.train_step(a[lo:hi], b[lo:hi], gt[lo:hi])
+    if rank == 0:
+        np.savez(out_path, grads=grads, weights=torch.cat([p["w"].reshape(-1) for p in tr.params]).cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_data_parallel_equals_full_batch(tmp_path):
+    """Two ranks with one pair each + gradient all-reduce == one rank with both pairs (the loss is a batch mean)."""
+    import torch.multiprocessing as mp
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_dp_worker, args=(2, 32500 + os.getpid() % 2000, out), nprocs=2, join=True)
+    got = np.load(out)
+    a, b, gt = data(2, 128, 128, 3)
+    tr = FlowNetSTrainer(W.init_weights("FlowNetS", 7), 2, 128, 128)
+    w0 = torch.cat([p["w"].reshape(-1) for p in tr.params]).cpu().numpy()
+    tr.forward_backward(a, b, gt)
+    want_g = tr.grad_arena.cpu().numpy()
+    tr.apply_gradients()
+    tr.train_step(a, b, gt)
+    want_w = torch.cat([p["w"].reshape(-1) for p in tr.params]).cpu().numpy()
+    assert np.abs(got["grads"] - want_g).max() < 1e-5 * np.abs(want_g).max()
+    # Adam turns a gradient of magnitude ~noise into a +-lr step: bound the fraction of such elements
+    move = np.abs(want_w - w0).max()
+    off = np.abs(got["weights"] - want_w) > 0.05 * move
+    assert off.mean() < 1e-4, off.mean()
