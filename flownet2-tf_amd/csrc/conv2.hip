@@ -30,6 +30,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef FN2_X2_ORDER
+#define FN2_X2_ORDER 0
+#endif
+
 namespace fn2 {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -46,7 +50,12 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   constexpr int NWI = BC / 32;  // weight-row DMA pieces per wave per stage (8 rows each)
   constexpr int NPI = BP / 32;  // pixel-row DMA pieces per wave per stage
   constexpr int ROWS = BC + BP;
-  __shared__ uint4 lds[2][ROWS * 8];
+  // two separate LDS objects, not lds[2][..]: the waitcnt pass only lets a ds_read run ahead of an in-flight
+  // LDS-DMA when it can prove (alias scopes of distinct LDS variables) that they touch different objects; with
+  // one array and a runtime buffer index it put s_waitcnt vmcnt(0) in front of every stage's first ds_read,
+  // i.e. the "prefetch" of stage s+1 was waited for BEFORE the MFMAs of stage s.
+  __shared__ uint4 lds0[ROWS * 8];
+  __shared__ uint4 lds1[ROWS * 8];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,19 +116,19 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   int ky = tap / p.KW, kx = tap - ky * p.KW;
   int wstage = kt0;  // absolute stage index of the next weight fetch
 
-  auto issue_piece = [&](auto piece_c, int buf) {
+  auto issue_piece = [&](auto piece_c, uint4* lds) {
     constexpr int i = decltype(piece_c)::value;
     if constexpr (i < NWI) {
       if (!(p.dbg & 2))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)&lds[buf][(wave * (BC / 4) + i * 8) * 8], 16, woff[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)&lds[(wave * (BC / 4) + i * 8) * 8], 16, woff[i],
                                                  wstage * 128, 0, 0);
     } else {
       constexpr int j = i - NWI;
       const unsigned tbit = (1u << ky) | (1u << (8 + kx));
       const int toff = ((ky * p.W + kx) * p.in_cs + sc * 8 * CH) * ESZ;
-      const unsigned voff = ((vmask[j] & tbit) == tbit) ? (unsigned)(roff[j] + toff) : kOobOffset;
+      const unsigned voff = ((vmask[j] & tbit) == tbit && wstage < kt1) ? (unsigned)(roff[j] + toff) : kOobOffset;
       if (!(p.dbg & 1))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)&lds[buf][(BC + wave * (BP / 4) + j * 8) * 8], 16, voff,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)&lds[(BC + wave * (BP / 4) + j * 8) * 8], 16, voff,
                                                  0, 0, 0);
     }
   };
@@ -130,9 +139,9 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       if (++kx == p.KW) { kx = 0; ++ky; }
     }
   };
-  auto issue_stage = [&](int buf) {
+  auto issue_stage = [&](uint4* lds) {
     [&]<int... I>(std::integer_sequence<int, I...>) {
-      (issue_piece(std::integral_constant<int, I>{}, buf), ...);
+      (issue_piece(std::integral_constant<int, I>{}, lds), ...);
     }(std::make_integer_sequence<int, NWI + NPI>{});
     advance();
   };
@@ -147,18 +156,14 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[tc][tp][q] = 0.f;
 
-  issue_stage(0);
+  issue_stage(lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // NOTE: nothing conditional may wrap the MFMAs: an `if` around them made hipcc shuttle all 64
-  // accumulators between VGPRs and AGPRs four times per stage (256 v_accvgpr moves, the dominant VALU
-  // cost of the first version of this loop -- found with SQ_INSTS_VALU and the .s).
-  for (int s = kt0; s < kt1; ++s) {
-    const int buf = (s - kt0) & 1;
-    if (s + 1 < kt1) issue_stage(buf ^ 1);  // next stage's DMA in flight under this stage's MFMAs
-    const uint4* A = &lds[buf][(wc * 64 + fr) * 8];
-    const uint4* B = &lds[buf][(BC + wp * 64 + fr) * 8];
+  // one stage of MFMAs on the LDS object `lds`
+  auto compute = [&](const uint4* lds) {
+    const uint4* A = &lds[(wc * 64 + fr) * 8];
+    const uint4* B = &lds[(BC + wp * 64 + fr) * 8];
     if constexpr (is_x2<T>::value) {
       // split fp16: the 128-byte row is [hi g0 | lo g0 | hi g1 | lo g1 | hi g2 | lo g2 | hi g3 | lo g3]
       // (4 groups of 8 channels).  One 32x32x16 product covers groups (2q, 2q+1): lane half h owns
@@ -181,44 +186,58 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
             acc[tc][tp] = mfma_32x32x16<f16_t>(ah[tc], bh[tp], acc[tc][tp]);
           }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      continue;
-    }
-    // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
-    uint4 fa[2][2], fb[2][2];
-    {
-      const int ch = fh ^ fsw;
-      fa[0][0] = A[ch]; fa[0][1] = A[32 * 8 + ch];
-      fb[0][0] = B[ch]; fb[0][1] = B[32 * 8 + ch];
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < 4) {
-        const int ch = ((ks + 1) * 2 + fh) ^ fsw;
-        fa[nxt][0] = A[ch]; fa[nxt][1] = A[32 * 8 + ch];
-        fb[nxt][0] = B[ch]; fb[nxt][1] = B[32 * 8 + ch];
+    } else {
+      // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
+      uint4 fa[2][2], fb[2][2];
+      {
+        const int ch = fh ^ fsw;
+        fa[0][0] = A[ch]; fa[0][1] = A[32 * 8 + ch];
+        fb[0][0] = B[ch]; fb[0][1] = B[32 * 8 + ch];
       }
-      if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-          for (int tp = 0; tp < 2; ++tp)
-            acc[tc][tp] = mfma_32x32x16<T>(fa[cur][tc], fb[cur][tp], acc[tc][tp]);
-      } else {
-        // chunk = 4 floats; MFMA j takes element j of both operands (a permutation of k shared by both)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < 4) {
+          const int ch = ((ks + 1) * 2 + fh) ^ fsw;
+          fa[nxt][0] = A[ch]; fa[nxt][1] = A[32 * 8 + ch];
+          fb[nxt][0] = B[ch]; fb[nxt][1] = B[32 * 8 + ch];
+        }
+        if constexpr (sizeof(T) == 2) {
 #pragma unroll
           for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp)
-              acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, fa[cur][tc])[j],
-                                                                 __builtin_bit_cast(f32x4, fb[cur][tp])[j],
-                                                                 acc[tc][tp], 0, 0, 0);
+              acc[tc][tp] = mfma_32x32x16<T>(fa[cur][tc], fb[cur][tp], acc[tc][tp]);
+        } else {
+          // chunk = 4 floats; MFMA j takes element j of both operands (a permutation of k shared by both)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+              for (int tp = 0; tp < 2; ++tp)
+                acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, fa[cur][tc])[j],
+                                                                   __builtin_bit_cast(f32x4, fb[cur][tp])[j],
+                                                                   acc[tc][tp], 0, 0, 0);
+        }
       }
     }
+  };
+
+  // NOTE: nothing conditional may wrap the MFMAs: an `if` around them made hipcc shuttle all 64
+  // accumulators between VGPRs and AGPRs four times per stage (256 v_accvgpr moves, the dominant VALU
+  // cost of the first version of this loop -- found with SQ_INSTS_VALU and the .s).
+  // Two stages per trip so that every LDS access names its object statically (see the lds0/lds1 note), and no
+  // branch between them: an odd stage count is rounded up with a stage whose pixel rows are all zero (the
+  // validity test in issue_piece fails for stages >= kt1), so its MFMAs add 0 * stale finite weights.
+  const int nst2 = (kt1 - kt0 + 1) & ~1;
+  for (int s = 0; s < nst2; s += 2) {
+    issue_stage(lds1);  // next stage's DMA in flight under this stage's MFMAs
+    compute(lds0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 2 < nst2) issue_stage(lds0);
+    compute(lds1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }

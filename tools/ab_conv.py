@@ -31,19 +31,24 @@ LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch
 def build(name, dtype):
     kind, k, stride, pad, cin, cout, N, H, Wd = LAYERS[name]
     lib = _hip.lib()
-    td = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[dtype]
-    code = {"f32": 0, "bf16": 1, "f16": 2}[dtype]
+    td = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f16x2": torch.float32}[dtype]
+    code = {"f32": 0, "bf16": 1, "f16": 2, "f16x2": 3}[dtype]
     rng = np.random.default_rng(0)
     cs_in = (cin + 63) // 64 * 64
     x = torch.zeros((N, H, Wd, cs_in), dtype=td, device="cuda")
-    x[..., :cin] = torch.from_numpy(rng.standard_normal((N, H, Wd, cin)).astype(np.float32)).cuda().to(td)
+    xin = np.zeros((N, H, Wd, cs_in), np.float32)
+    xin[..., :cin] = rng.standard_normal((N, H, Wd, cin)).astype(np.float32)
+    if dtype == "f16x2":
+        x = torch.from_numpy(W.split_f16x2(xin).view(np.float32)).cuda()
+    else:
+        x = torch.from_numpy(xin).cuda().to(td)
     if kind == "conv":
         w = rng.standard_normal((k, k, cin, cout)).astype(np.float32) * 0.05
         oh, ow = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
     else:
         w = rng.standard_normal((4, 4, cout, cin)).astype(np.float32) * 0.05
         oh, ow = 2 * H, 2 * Wd
-    esz = 4 if dtype == "f32" else 2
+    esz = 2 if dtype in ("bf16", "f16") else 4
     line = 128 // esz
     cin_line = (cin + line - 1) // line * line
     cin_pad = cin_line if _hip.conv_plan(code, cin_line, cout).layout == 1 else (cin + 7) // 8 * 8
@@ -51,10 +56,10 @@ def build(name, dtype):
     pack = W.pack_conv if kind == "conv" else W.pack_deconv
     packed, cin_pad, cout_pad, kpad = pack(w, plan.cout_tile, plan.kstep_elems, cin_pad, plan.layout)
     layout = plan.layout
-    wdev = torch.from_numpy(packed).cuda().to(td).contiguous()
+    wdev = W.packed_to_device(packed, plan.wgt_dtype, "cuda")
     out = torch.zeros((N, oh, ow, (cout + 63) // 64 * 64), dtype=td, device="cuda")
     d = _hip.Fn2ConvDesc()
-    d.inp, d.out = _hip.view(x, cin, 0), _hip.view(out, cout, 0)
+    d.inp, d.out = _hip.view(x, cin, 0, code), _hip.view(out, cout, 0, code)
     d.wgt, d.bias = wdev.data_ptr(), None
     d.kind = 0 if kind == "conv" else 1
     d.kh = d.kw = k
@@ -76,8 +81,17 @@ def main():
     ap.add_argument("--layers", default=",".join(LAYERS))
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--inner", type=int, default=5)
+    ap.add_argument("--libs", default="", help="comma list of alternative builds of the library (tools/build_variant.sh); "
+                    "a variant 'L<i>:<dbg>' runs build i (0 = the in-tree library)")
     a = ap.parse_args()
     lib = _hip.lib()
+    libs = [lib]
+    for path in [p for p in a.libs.split(",") if p]:
+        l = C.CDLL(os.path.abspath(path))
+        for name, (res, args) in _hip.PROTOTYPES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        libs.append(l)
     variants = [v for v in a.variants.split(",")]
     for name in a.layers.split(","):
         d, flop, keep = build(name, a.dtype)
@@ -85,11 +99,13 @@ def main():
         s = _hip.stream_ptr()
         for r in range(a.rounds + 2):
             for v in variants:
-                os.environ["FN2_CONV_DBG"] = v
+                li, dbg = (v[1:].split(":") + ["0"])[:2] if v.startswith("L") else ("0", v)
+                os.environ["FN2_CONV_DBG"] = dbg
+                run = libs[int(li)].fn2_conv2d
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.inner):
-                    _hip.check(lib.fn2_conv2d(C.byref(d), s))
+                    _hip.check(run(C.byref(d), s))
                 e1.record()
                 torch.cuda.synchronize()
                 if r >= 2:
