@@ -41,7 +41,10 @@ __global__ void __launch_bounds__(256) corr2_kernel(const CorrArgs p, const int 
   constexpr int WPX = C2_WIN * 16;
   constexpr int NPIECE = WPX * SG / 8;  // DMA wave-instructions per stage (8 rows of 128 B each)
   constexpr int PPW = (NPIECE + 3) / 4;
-  __shared__ uint4 lds[2][SG][WPX * 8];
+  // two LDS objects (not lds[2][..]): lets the waitcnt pass prove that a stage's ds_reads do not touch the object the
+  // next stage's LDS-DMA is filling (see conv2.hip); the buffer choice is static when NSTAGE is even
+  __shared__ uint4 lds0[SG][WPX * 8];
+  __shared__ uint4 lds1[SG][WPX * 8];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(256) corr2_kernel(const CorrArgs p, const int 
     voff[k] = ok ? (unsigned)((xw * p.b_cs + p.b_c0) * ESZ + sl * 128 + G * 16) : kOob;
   }
   const unsigned row_bytes = (unsigned)(p.W * p.b_cs * ESZ);
-  auto issue_stage = [&](int it, int buf) {
+  auto issue_stage = [&](int it, uint4 (*lds)[WPX * 8]) {
     const int pi = p_lo + it / NSTAGE, st = it - (it / NSTAGE) * NSTAGE;
     const int yb = y + (pi - p.gr) * p.s2;
     const int soff = (n * p.H + yb) * (int)row_bytes + st * SG * 128;
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(256) corr2_kernel(const CorrArgs p, const int 
       const int q = wave + 4 * k;
       if (q < NPIECE) {
         const int sl = q / (WPX / 8), rg = q - sl * (WPX / 8);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)&lds[buf][sl][rg * 64], 16, voff[k], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)&lds[sl][rg * 64], 16, voff[k], soff, 0, 0);
       }
     }
   };
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(256) corr2_kernel(const CorrArgs p, const int 
   const int fsw = (fi >> 1) & 7;
   f32x4 acc[C2_NBT];
   const int niter = np * NSTAGE;
-  issue_stage(0, 0);
+  issue_stage(0, lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int pidx = 0; pidx < np; ++pidx) {
@@ -123,14 +126,15 @@ __global__ void __launch_bounds__(256) corr2_kernel(const CorrArgs p, const int 
 #pragma unroll
     for (int st = 0; st < NSTAGE; ++st) {
       const int it = pidx * NSTAGE + st;
-      const int buf = it & 1;
-      if (it + 1 < niter) issue_stage(it + 1, buf ^ 1);
+      const int buf = (NSTAGE % 2 == 0) ? (st & 1) : (it & 1);
+      uint4 (*lds)[WPX * 8] = buf ? lds1 : lds0;
+      if (it + 1 < niter) issue_stage(it + 1, buf ? lds0 : lds1);
 #pragma unroll
       for (int sl = 0; sl < SG; ++sl) {
         const int l = st * SG + sl;
 #pragma unroll
         for (int tb = 0; tb < C2_NBT; ++tb) {
-          const uint4* row = &lds[buf][sl][((tb0 + tb) * 16 + fi) * 8];
+          const uint4* row = &lds[sl][((tb0 + tb) * 16 + fi) * 8];
           const uint4 b0 = row[fg ^ fsw], b1 = row[(4 + fg) ^ fsw];
           if constexpr (X2) {  // b0 = hi, b1 = lo of group fg; fa[l][0] = hi, fa[l][1] = lo
             acc[tb] = mfma_16x16x32<f16_t>(fa[l][1], b0, acc[tb]);

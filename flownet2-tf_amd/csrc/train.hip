@@ -329,7 +329,10 @@ template <bool SWAP>
 __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PK = 32;  // pixels per stage
-  __shared__ float lds[2][2][PK * 128];  // [buf][dense | sampled][pixel][channel]
+  // [dense | sampled][pixel][channel] x 2 stages; separate LDS objects so the waitcnt pass lets the ds_reads of one
+  // stage run while the LDS-DMA of the next is in flight (see conv2.hip)
+  __shared__ float lds0[2][PK * 128];
+  __shared__ float lds1[2][PK * 128];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1;
@@ -356,18 +359,18 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
     const int n = pix / (p.DH * p.DW_), rem = pix - n * (p.DH * p.DW_);
     sn[k] = n; sy[k] = rem / p.DW_; sx[k] = rem - sy[k] * p.DW_;
   }
-  auto issue = [&](int st, int buf) {
+  auto issue = [&](int st, float (*lds)[PK * 128]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = (wave * 4 + k) * 2;          // first of the 2 rows of this piece (wave-uniform)
       const int pix = pbeg + st * PK + r + lrow;  // this lane's pixel
       const bool pv = pix < pend;
       const unsigned vd = (pv && ch_ok_d) ? (unsigned)((pix * p.dn_cs + p.dn_c0 + i0 + lch) * 4) : kOobT;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[buf][0][r * 128], 16, vd, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, vd, 0, 0, 0);
       const int iy = sy[k] * p.stride + ky - p.pad, ix = sx[k] * p.stride + kx - p.pad;
       const bool sv = pv && ch_ok_s && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
       const unsigned vs = sv ? (unsigned)((((sn[k] * p.SH + iy) * p.SW + ix) * p.sm_cs + p.sm_c0 + j0 + lch) * 4) : kOobT;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[buf][1][r * 128], 16, vs, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[1][r * 128], 16, vs, 0, 0, 0);
       // advance this row by PK pixels for the next stage
       sx[k] += PK;
       while (sx[k] >= p.DW_) { sx[k] -= p.DW_; if (++sy[k] == p.DH) { sy[k] = 0; ++sn[k]; } }
@@ -383,14 +386,9 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
   const int fr = lane & 31, fk = lane >> 5;
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nstage) issue(st + 1, buf ^ 1);
-    const float* Dn = &lds[buf][0][wi * 64 + fr];
-    const float* Sm = &lds[buf][1][wj * 64 + fr];
+  auto compute = [&](const float (*lds)[PK * 128]) {
+    const float* Dn = &lds[0][wi * 64 + fr];
+    const float* Sm = &lds[1][wj * 64 + fr];
 #pragma unroll
     for (int kk = 0; kk < PK; kk += 2) {
       const int row = (kk + fk) * 128;
@@ -407,6 +405,19 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
+  };
+  issue(0, lds0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // two stages per trip, no branch around the MFMAs: a stage past the pixel range loads zeros (pix >= pend)
+  const int nstage2 = (nstage + 1) & ~1;
+  for (int st = 0; st < nstage2; st += 2) {
+    issue(st + 1, lds1);
+    compute(lds0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 2 < nstage2) issue(st + 2, lds0);
+    compute(lds1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
