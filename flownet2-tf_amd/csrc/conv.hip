@@ -532,7 +532,7 @@ int fn2_conv2d_plan(int in_dtype, int cin_pad, int cout, fn2_conv_plan* plan) {
     return FN2_OK;
   }
   if (conv_fast_ok(in_dtype, cin_pad, cout)) {
-    plan->layout = 1; plan->cout_tile = cout > 64 ? 128 : 64; plan->kstep_elems = 128 / esz;
+    plan->layout = 1; plan->cout_tile = cout > 64 ? 128 : cout > 32 ? 64 : 32; plan->kstep_elems = 128 / esz;
     plan->wgt_dtype = in_dtype;
     return FN2_OK;
   }
@@ -668,7 +668,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
 // Preferred split-K factor: fill >= ~2 blocks per CU on layers whose output grid is small
 // (the 6x8 .. 24x32 resolution layers: weight-bandwidth bound, SURVEY.md section 7 "hard parts").
 static int preferred_split(const ConvArgs& a, int tile, int phases) {
-  const int bp = tile == 128 ? 128 : 256;
+  const int bp = tile == 128 ? 128 : 256;  // 64- and 32-cout tiles span 256 pixels
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
   if (blocks >= 384) return 1;
   int s = (int)((512 + blocks - 1) / blocks);

@@ -40,12 +40,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr unsigned kOobOffset = 0x80000000u;  // >= num_records of every descriptor (tensors < 2 GiB)
 
-template <typename T, typename OutT, int WC, int WP>
+// TCN = 32-cout MFMA tiles per wave (2: the 128x128 / 64x256 blocks; 1: a 32-cout x 256-pixel block for the
+// Cout <= 32 layers -- full-resolution fusion layers, conv_redir -- whose 64-cout tile was half or more padding).
+template <typename T, typename OutT, int WC, int WP, int TCN = 2>
 __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
   constexpr int ESZ = (int)sizeof(T);
-  constexpr int BC = WC * 64, BP = WP * 64;
+  constexpr int BC = WC * TCN * 32, BP = WP * 64;
   static_assert(WC * WP == 4, "4 waves per block");
   constexpr int NWI = BC / 32;  // weight-row DMA pieces per wave per stage (8 rows each)
   constexpr int NPI = BP / 32;  // pixel-row DMA pieces per wave per stage
@@ -72,8 +74,21 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   }
   const int kt0 = split * p.kper;
   const int kt1 = min(p.ksteps, kt0 + p.kper);
-  const int m0 = blockIdx.x * BP;
-  const int c0 = blockIdx.y * BC;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id
+  // order, so with the plain mapping a pixel tile's vertical neighbours and its other cout tiles run on other
+  // XCDs / much later: every 3x3 halo row and every extra cout tile re-read the activations from HBM.  Give
+  // XCD i a contiguous band of the (pixel tile, cout tile) space, cout tile fastest: consecutive blocks of one
+  // XCD share the input tile, then move to the adjacent one (halo rows still in that XCD's L2).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (!(p.dbg & 4)) {
+    const int NT = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = L & 7, chunk = NT >> 3, rem = NT & 7;
+    const int Lp = xcd * chunk + min(xcd, rem) + (L >> 3);
+    bx = Lp / (int)gridDim.y;
+    by = Lp - bx * (int)gridDim.y;
+  }
+  const int m0 = bx * BP;
+  const int c0 = by * BC;
 
   // buffer descriptors: base, stride 0, num_records bytes, raw dword format
   const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, (int)(p.cout_pad * wrow_bytes), 0x00020000);
@@ -148,9 +163,9 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 
   // ---- fragment addresses: row r = l&31 of a 32-row tile, chunk 2*ks + (l>>5), swizzled by the row
   const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-  f32x16 acc[2][2];
+  f32x16 acc[TCN][2];
 #pragma unroll
-  for (int tc = 0; tc < 2; ++tc)
+  for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
@@ -162,7 +177,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 
   // one stage of MFMAs on the LDS object `lds`
   auto compute = [&](const uint4* lds) {
-    const uint4* A = &lds[(wc * 64 + fr) * 8];
+    const uint4* A = &lds[(wc * TCN * 32 + fr) * 8];
     const uint4* B = &lds[(BC + wp * 64 + fr) * 8];
     if constexpr (is_x2<T>::value) {
       // split fp16: the 128-byte row is [hi g0 | lo g0 | hi g1 | lo g1 | hi g2 | lo g2 | hi g3 | lo g3]
@@ -171,14 +186,13 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
-        uint4 ah[2], al[2], bh[2], bl[2];
+        uint4 ah[TCN], al[TCN], bh[2], bl[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          ah[t] = A[t * 32 * 8 + chh]; al[t] = A[t * 32 * 8 + chl];
-          bh[t] = B[t * 32 * 8 + chh]; bl[t] = B[t * 32 * 8 + chl];
-        }
+        for (int t = 0; t < TCN; ++t) { ah[t] = A[t * 32 * 8 + chh]; al[t] = A[t * 32 * 8 + chl]; }
 #pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
+        for (int t = 0; t < 2; ++t) { bh[t] = B[t * 32 * 8 + chh]; bl[t] = B[t * 32 * 8 + chl]; }
+#pragma unroll
+        for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
           for (int tp = 0; tp < 2; ++tp) {
             acc[tc][tp] = mfma_32x32x16<f16_t>(al[tc], bh[tp], acc[tc][tp]);
@@ -188,10 +202,11 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       }
     } else {
       // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
-      uint4 fa[2][2], fb[2][2];
+      uint4 fa[2][TCN], fb[2][2];
       {
         const int ch = fh ^ fsw;
-        fa[0][0] = A[ch]; fa[0][1] = A[32 * 8 + ch];
+#pragma unroll
+        for (int t = 0; t < TCN; ++t) fa[0][t] = A[t * 32 * 8 + ch];
         fb[0][0] = B[ch]; fb[0][1] = B[32 * 8 + ch];
       }
 #pragma unroll
@@ -199,12 +214,13 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
         const int cur = ks & 1, nxt = cur ^ 1;
         if (ks + 1 < 4) {
           const int ch = ((ks + 1) * 2 + fh) ^ fsw;
-          fa[nxt][0] = A[ch]; fa[nxt][1] = A[32 * 8 + ch];
+#pragma unroll
+          for (int t = 0; t < TCN; ++t) fa[nxt][t] = A[t * 32 * 8 + ch];
           fb[nxt][0] = B[ch]; fb[nxt][1] = B[32 * 8 + ch];
         }
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
-          for (int tc = 0; tc < 2; ++tc)
+          for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp)
               acc[tc][tp] = mfma_32x32x16<T>(fa[cur][tc], fb[cur][tp], acc[tc][tp]);
@@ -213,7 +229,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int tc = 0; tc < 2; ++tc)
+            for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
               for (int tp = 0; tp < 2; ++tp)
                 acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, fa[cur][tc])[j],
@@ -255,10 +271,10 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
       float* po = slab + (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.ws_cs;
 #pragma unroll
-      for (int tc = 0; tc < 2; ++tc)
+      for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int co = c0 + wc * 64 + tc * 32 + fh * 16 + q * 4;
+          const int co = c0 + wc * TCN * 32 + tc * 32 + fh * 16 + q * 4;
           if (co < p.ws_cs)
             *reinterpret_cast<float4*>(po + co) = make_float4(acc[tc][tp][4 * q], acc[tc][tp][4 * q + 1],
                                                               acc[tc][tp][4 * q + 2], acc[tc][tp][4 * q + 3]);
@@ -268,8 +284,8 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   }
   const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
 #pragma unroll
-  for (int tc = 0; tc < 2; ++tc) {
-    const int cout_base = c0 + wc * 64 + tc * 32 + fh * 16;
+  for (int tc = 0; tc < TCN; ++tc) {
+    const int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
     float bias[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) bias[q] = (p.bias != nullptr && cout_base + q < p.Cout) ? p.bias[cout_base + q] : 0.f;
@@ -311,9 +327,12 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   if (tile == 128) {
     dim3 grid(cdiv(a.M, 128), a.cout_pad / 128, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2>), grid, block, 0, s, a);
-  } else {
+  } else if (tile == 64) {
     dim3 grid(cdiv(a.M, 256), a.cout_pad / 64, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4>), grid, block, 0, s, a);
+  } else {
+    dim3 grid(cdiv(a.M, 256), a.cout_pad / 32, z);
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4, 1>), grid, block, 0, s, a);
   }
   FN2_CHECK_LAUNCH("conv_igemm2");
   return FN2_OK;
@@ -325,7 +344,7 @@ bool conv_fast_ok(int in_dtype, int cin_pad, int cout) {
 }
 
 int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s) {
-  if (tile != 128 && tile != 64) return fail(FN2_ERR_UNSUPPORTED, "conv fast path: cout tile %d", tile);
+  if (tile != 128 && tile != 64 && tile != 32) return fail(FN2_ERR_UNSUPPORTED, "conv fast path: cout tile %d", tile);
   if (in_dtype == FN2_F32) return launch2<float, float>(a, tile, phases, s);
   if (in_dtype == FN2_BF16) {
     if (out_dtype == FN2_BF16) return launch2<bf16_t, bf16_t>(a, tile, phases, s);

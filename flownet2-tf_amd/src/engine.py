@@ -28,6 +28,7 @@ from . import _hip, netdefs, weights as W
 # on the fp16 matrix cores; buffers are float32 containers (4 bytes per channel).
 _DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f16x2": torch.float32}
 _CODE = {"f32": _hip.FN2_F32, "bf16": _hip.FN2_BF16, "f16": _hip.FN2_F16, "f16x2": _hip.FN2_F16X2}
+_TILE_ARGS = {128: "2, 2, 2", 64: "1, 4, 2", 32: "1, 4, 1"}  # conv_igemm2_kernel<.., WC, WP, TCN> per cout tile
 _TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16", "f16x2": "fn2::x2_t"}
 
 
@@ -67,9 +68,10 @@ class Engine:
     def _buf(self, name, n, h, w, c, dtype=None, stem=False):
         """Activation buffer.  dtype=torch.float32: dense fp32 (flow heads, final flows).  stem=True: a
         packed network input (few channels, spatially pre-padded by its builder kernel)."""
-        # channel stride: multiples of 64 keep every consumer on the LDS-DMA conv kernel
-        # (a tap's channel run is then whole 128-byte lines); small stems stay at multiples of 8
-        cs = (_round_up(c, 64) if c > 32 else _round_up(c, 8)) if dtype is None else c
+        # channel stride: whole 128-byte lines (64 channels of a 2-byte format, 32 of a 4-byte one) keep every
+        # consumer on the LDS-DMA conv kernel; small stems stay at multiples of 8
+        line = 64 if self.act_code in (_hip.FN2_BF16, _hip.FN2_F16) else 32
+        cs = (_round_up(c, line) if c > 32 else _round_up(c, 8)) if dtype is None else c
         t = torch.zeros((n, h, w, cs), dtype=self.tdtype if dtype is None else dtype, device=self.device)
         assert name not in self.bufs, name
         self.bufs[name] = t
@@ -143,7 +145,7 @@ class Engine:
             kern = f"flow_head_kernel<{tn}>"
         elif layout == 1:
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
-            kern = f"conv_igemm2_kernel<{tn}, {on}, {'2, 2' if tile == 128 else '1, 4'}>"
+            kern = f"conv_igemm2_kernel<{tn}, {on}, {_TILE_ARGS[tile]}>"
         else:
             shape = {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4", 16: "1, 1, 4"}[tile]
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
@@ -193,7 +195,7 @@ class Engine:
                                 kstep=plan.kstep_elems, cs=cs))
         tn = _TNAME[self.dtype_name]
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
-                 kernel=f"conv_igemm2_kernel<{tn}, {tn}, {'2, 2' if plan.cout_tile == 128 else '1, 4'}>")
+                 kernel=f"conv_igemm2_kernel<{tn}, {tn}, {_TILE_ARGS[plan.cout_tile]}>")
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * k * k * cin * cout))
 

@@ -154,7 +154,8 @@ class FlowNetSTrainer:
         self.keep += [d, wb, gmap]
         self.eng.conv_descs.append(d)  # shares the split-K workspace
         if plan.layout == 1:
-            d.kernel_name = "conv_igemm2_kernel<float, float, %s>" % ("2, 2" if plan.cout_tile == 128 else "1, 4")
+            from .engine import _TILE_ARGS
+            d.kernel_name = "conv_igemm2_kernel<float, float, %s>" % _TILE_ARGS[plan.cout_tile]
         else:
             d.kernel_name = "conv_igemm_kernel<float, float, %s>" % {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4",
                                                                       16: "1, 1, 4"}[plan.cout_tile]

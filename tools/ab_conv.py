@@ -25,6 +25,11 @@ LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch
     "conv6_1": ("conv", 3, 1, 1, 1024, 1024, 8, 6, 8),
     "deconv3": ("deconv", 4, 2, 1, 770, 128, 8, 24, 32),
     "deconv2": ("deconv", 4, 2, 1, 386, 64, 8, 48, 64),
+    # FlowNet2 batch 4: the full-resolution fusion layers and the SD stem
+    "fuse_interconv0": ("conv", 3, 1, 1, 82, 16, 4, 384, 512),
+    "fuse_interconv1": ("conv", 3, 1, 1, 162, 32, 4, 192, 256),
+    "fuse_deconv0": ("deconv", 4, 2, 1, 162, 16, 4, 192, 256),
+    "fuse_conv1_1": ("conv", 3, 1, 1, 64, 128, 4, 192, 256),
 }
 
 
