@@ -417,6 +417,34 @@ static int launch_conv(const ConvArgs& a, int tile, int phases_, hipStream_t s) 
   return FN2_OK;
 }
 
+// Second half of a flow head computed as a GEMM: fn2_conv2d first runs the head as a 1x1 convolution with
+// 18 outputs, t[pix][tap*2 + co] = sum_ci x[pix][ci] * w[tap][ci][co] (the activations are read ONCE, on the
+// matrix cores, instead of nine times by the dot-product kernel); this kernel adds the nine shifted partials:
+//   out[n,y,x,co] = bias[co] + sum_{ky,kx} t[n, y+ky-1, x+kx-1][(ky*3+kx)*2 + co]    (zero outside the image)
+__global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __restrict__ t, int t_cs,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int N, int H, int W) {
+  const long total = (long)N * H * W;
+  const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    float a0 = b0, a1 = b1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = x + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const float2 v = *reinterpret_cast<const float2*>(t + (i + (long)(ky - 1) * W + (kx - 1)) * t_cs + (ky * 3 + kx) * 2);
+        a0 += v.x; a1 += v.y;
+      }
+    }
+    *reinterpret_cast<float2*>(out + 2 * i) = make_float2(a0, a1);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // upsample_flowXtoY: 2 -> 2 channel transposed conv 4x4 s2 crop 1, linear (flownet_s.py:60-63).
 // HBM-bound: one lane per output pixel.
@@ -755,6 +783,15 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     hipLaunchKernelGGL(splitk_finalize_kernel<f16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (f16_t*)a.out,
                        npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
   FN2_CHECK_LAUNCH("splitk_finalize");
+  return FN2_OK;
+}
+
+int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out, int n, int h, int w, void* stream) {
+  FN2_REQUIRE(t && out, "flow_head_gather: null pointer");
+  FN2_REQUIRE(t_cs >= 18 && t_cs % 2 == 0 && n >= 1 && h >= 1 && w >= 1, "flow_head_gather: t must hold 18 partials per pixel");
+  hipLaunchKernelGGL(flow_head_gather_kernel, dim3(grid_for((long)n * h * w, 256)), dim3(256), 0, (hipStream_t)stream, t,
+                     t_cs, bias, out, n, h, w);
+  FN2_CHECK_LAUNCH("flow_head_gather");
   return FN2_OK;
 }
 

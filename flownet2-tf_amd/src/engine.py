@@ -20,6 +20,7 @@ weights 16-bit, fp32 accumulate, flow heads / warps / resize in fp32).
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _hip, netdefs, weights as W
@@ -37,7 +38,7 @@ def _round_up(x, m):
 
 
 class Engine:
-    def __init__(self, model, weights, batch, height, width, dtype="f32", device=None):
+    def __init__(self, model, weights, batch, height, width, dtype="f32", device=None, heads_as_gemm=True):
         if model not in netdefs.MODELS:
             raise ValueError("unknown model %r" % model)
         if dtype not in _DT:
@@ -61,6 +62,10 @@ class Engine:
         self.graph = None
         self.conv_descs = []
         self.layers = []   # one record per parameterised layer, in forward order (used by the trainer)
+        # flow heads as 1x1 GEMM (18 partial outputs per pixel) + gather; the trainer keeps the dot-product
+        # head, whose natural-order weight its backward kernels read
+        self.heads_as_gemm = heads_as_gemm
+        self._head_t = None
         self.outputs = self._build()
         self._alloc_workspace()
 
@@ -97,6 +102,9 @@ class Engine:
         sbuf, sc0, sc = src
         dbuf, dc0, dc = dst
         assert sc == cin and dc == cout, (scope, name, sc, cin, dc, cout)
+        if (self.heads_as_gemm and kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1 and not act
+                and dbuf.dtype == torch.float32 and self._head_gemm(scope, spec, src, dst)):
+            return
         wname = f"{scope}/{name}/weights"
         in_code = self._code(sbuf)
         esz = 2 if in_code in (_hip.FN2_BF16, _hip.FN2_F16) else 4
@@ -154,6 +162,52 @@ class Engine:
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         taps = k * k if kind == "conv" else 4
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * taps * cin * cout))
+
+    def _head_gemm(self, scope, spec, src, dst):
+        """predict_flowN as a GEMM: 1x1 convolution with 18 outputs (tap*2 + co) on the LDS-DMA kernel into a shared
+        fp32 scratch tensor, then fn2_flow_head_gather.  Returns False when the input slice has no whole-line run."""
+        name, kind, k, stride, pad, cin, cout, act = spec
+        sbuf, sc0, sc = src
+        pf = dst[0]
+        in_code = self._code(sbuf)
+        esz = 2 if in_code in (_hip.FN2_BF16, _hip.FN2_F16) else 4
+        cin_line = _round_up(cin, 128 // esz)
+        if sc0 + cin_line > sbuf.shape[3]:
+            return False
+        plan = _hip.conv_plan(in_code, cin_line, 18)
+        if plan.layout != 1:
+            return False
+        w = np.asarray(self.weights[f"{scope}/{name}/weights"], np.float32)          # [3,3,cin,2] HWIO
+        w1 = np.ascontiguousarray(w.transpose(2, 0, 1, 3)).reshape(1, 1, cin, 18)     # [ci][(ky*3+kx)*2+co]
+        packed, cin_pad, cout_pad, kpad = W.pack_conv(w1, plan.cout_tile, plan.kstep_elems, cin_line, plan.layout)
+        out_scale = 1.0
+        if plan.wgt_dtype == _hip.FN2_F16X2:
+            wmax = float(abs(packed).max())
+            if wmax > 0:
+                k2 = int(math.floor(math.log2(1024.0 / wmax)))
+                packed, out_scale = packed * (2.0 ** k2), 2.0 ** (-k2)
+        wdev = W.packed_to_device(packed, plan.wgt_dtype, self.device)
+        bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
+        if self._head_t is None:  # one scratch for every head: launches are ordered on one stream
+            self._head_t = torch.zeros((self.N * self.H * self.W, 32), dtype=torch.float32, device=self.device)
+        n, h, wd = pf.shape[0], pf.shape[1], pf.shape[2]
+        d = _hip.Fn2ConvDesc()
+        d.inp = self._v(sbuf, sc, sc0)
+        d.out = _hip.Fn2Tensor(self._head_t.data_ptr(), _hip.FN2_F32, n, h, wd, 18, 32, 0)
+        d.wgt, d.bias = wdev.data_ptr(), None
+        d.kind, d.kh, d.kw, d.stride, d.pad = 0, 1, 1, 1, 0
+        d.act = _hip.ACT_NONE
+        d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, plan.layout
+        d.out_scale = out_scale
+        self.keep += [d, wdev, bias]
+        self.conv_descs.append(d)
+        tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
+        self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
+                 kernel=f"conv_igemm2_kernel<{tn}, float, {_TILE_ARGS[plan.cout_tile]}>")
+        self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(self._head_t), 32, _hip.ptr(bias),
+                 _hip.ptr(pf), n, h, wd)
+        self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
+        return True
 
     def _conv_stem(self, scope, spec, sbuf, dst):
         """First layer of a network on its pre-padded few-channel input: kind-2 row-run convolution

@@ -52,7 +52,7 @@ def _index_hwio(rec):
 
 class FlowNetSTrainer:
     def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8):
-        self.eng = Engine("FlowNetS", weights, batch, height, width, "f32")
+        self.eng = Engine("FlowNetS", weights, batch, height, width, "f32", heads_as_gemm=False)
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
         self.schedule, self.eps = schedule, eps

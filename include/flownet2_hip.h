@@ -171,6 +171,10 @@ int fn2_conv2d_plan(int in_dtype, int cin_pad, int cout, fn2_conv_plan* plan);
 int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d);
 int fn2_conv2d(const fn2_conv_desc* d, void* stream);
 
+/* Flow head (predict_flowN: 3x3, stride 1, pad 1, 2 outputs; flownet_s.py:54-56) as a GEMM: run fn2_conv2d as a
+ * 1x1 convolution with 18 outputs t[pix][tap*2+co] (weight w1x1[ci][tap*2+co] = w[ky][kx][ci][co]) into an fp32
+ * scratch tensor, then this call: out[n,y,x,co] = bias[co] + sum_taps t[n,y+ky-1,x+kx-1][tap*2+co].  out dense [n,h,w,2]. */
+int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out, int n, int h, int w, void* stream);
 /* upsample_flowXtoY: 2->2 channel conv-transpose 4x4 s2 crop 1, linear, no bias (flownet_s.py:60-63).
  * in: fp32 [n,h,w,2] dense; w: fp32 [4][4][2 out][2 in] (reference HW-O-I layout); out: view with c=2. */
 int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, int n, int h, int wd,

@@ -58,10 +58,11 @@ def test_conv_plan_rules(hip):
     assert plan(hip.FN2_BF16, 32, 128) == (0, 128, 32, hip.FN2_BF16)   # 64 bytes per tap: generic kernel
     assert plan(hip.FN2_F32, 32, 64) == (1, 64, 32, hip.FN2_F32)
     assert plan(hip.FN2_F32, 8, 64) == (0, 64, 16, hip.FN2_F32)        # stem
-    assert plan(hip.FN2_F16, 256, 32) == (1, 64, 64, hip.FN2_F16)      # small Cout rides the 64-row tile
+    assert plan(hip.FN2_F16, 256, 32) == (1, 32, 64, hip.FN2_F16)      # Cout <= 32: the 32-cout x 256-pixel tile
+    assert plan(hip.FN2_F16, 256, 48) == (1, 64, 64, hip.FN2_F16)
     assert plan(hip.FN2_BF16, 256, 2) == (0, 16, 32, hip.FN2_BF16)     # flow head
     assert plan(hip.FN2_F16X2, 256, 2) == (0, 16, 16, hip.FN2_F32)     # flow head on split fp16: fp32 weights
-    assert plan(hip.FN2_F16X2, 96, 16) == (1, 64, 32, hip.FN2_F16X2)
+    assert plan(hip.FN2_F16X2, 96, 16) == (1, 32, 32, hip.FN2_F16X2)
     with pytest.raises(NotImplementedError):
         hip.conv_plan(hip.FN2_F16X2, 8, 64)                            # split fp16 has no generic input path
     with pytest.raises(ValueError):
