@@ -40,6 +40,25 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr unsigned kOobOffset = 0x80000000u;  // >= num_records of every descriptor (tensors < 2 GiB)
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor: base, stride 0, num_records bytes, raw dword format
+__device__ __forceinline__ v4i_t make_rsrc(const void* base, int bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return v4i_t{(int)(a & 0xffffffffu), (int)((a >> 32) & 0xffffu), bytes, 0x00020000};
+}
+
+// 16 bytes per lane, global/L2 -> LDS (lane-linear from `lds`), as inline asm: the compiler's waitcnt pass then
+// knows nothing about these LDS writes, and every wait on them is the explicit s_waitcnt in the pipeline code
+// below.  (With the builtin, the pass protects each later ds_read itself; it proves independence only for
+// distinct LDS objects, and in the 3-slot ring it still put a vmcnt(0) -- a wait for the stage issued a few
+// instructions earlier -- at the loop header.)
+__device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigned voff, int soff) {
+  const unsigned la = (unsigned)(unsigned long long)(lptr_t)lds;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(la), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 // TCN = 32-cout MFMA tiles per wave (2: the 128x128 / 64x256 blocks; 1: a 32-cout x 256-pixel block for the
 // Cout <= 32 layers -- full-resolution fusion layers, conv_redir -- whose 64-cout tile was half or more padding).
 template <typename T, typename OutT, int WC, int WP, int TCN = 2>
@@ -91,8 +110,8 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   const int c0 = by * BC;
 
   // buffer descriptors: base, stride 0, num_records bytes, raw dword format
-  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(wgt), 0, (int)(p.cout_pad * wrow_bytes), 0x00020000);
-  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const v4i_t rsrc_w = make_rsrc(wgt, (int)(p.cout_pad * wrow_bytes));
+  const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
 
   // ---- per-lane DMA offsets.  Lane -> (row lane>>3 of the piece's 8 rows, physical chunk lane&7)
   const int lrow = lane >> 3, lphys = lane & 7;
@@ -135,16 +154,14 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     constexpr int i = decltype(piece_c)::value;
     if constexpr (i < NWI) {
       if (!(p.dbg & 2))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t)&lds[(wave * (BC / 4) + i * 8) * 8], 16, woff[i],
-                                                 wstage * 128, 0, 0);
+        dma16(rsrc_w, &lds[(wave * (BC / 4) + i * 8) * 8], woff[i], wstage * 128);
     } else {
       constexpr int j = i - NWI;
       const unsigned tbit = (1u << ky) | (1u << (8 + kx));
       const int toff = ((ky * p.W + kx) * p.in_cs + sc * 8 * CH) * ESZ;
       const unsigned voff = ((vmask[j] & tbit) == tbit && wstage < kt1) ? (unsigned)(roff[j] + toff) : kOobOffset;
       if (!(p.dbg & 1))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lptr_t)&lds[(BC + wave * (BP / 4) + j * 8) * 8], 16, voff,
-                                                 0, 0, 0);
+        dma16(rsrc_x, &lds[(BC + wave * (BP / 4) + j * 8) * 8], voff, 0);
     }
   };
   auto advance = [&]() {
@@ -170,10 +187,6 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[tc][tp][q] = 0.f;
-
-  issue_stage(lds0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   // one stage of MFMAs on the LDS object `lds`
   auto compute = [&](const uint4* lds) {
@@ -246,6 +259,11 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   // Two stages per trip so that every LDS access names its object statically (see the lds0/lds1 note), and no
   // branch between them: an odd stage count is rounded up with a stage whose pixel rows are all zero (the
   // validity test in issue_piece fails for stages >= kt1), so its MFMAs add 0 * stale finite weights.
+  // (Measured and dropped: a 3-slot ring with the DMA two stages ahead.  96 KB of LDS = one block per CU, and
+  // losing the second block's MFMAs under this block's waits cost 20-30% on every layer, bf16 and split fp16.)
+  issue_stage(lds0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   const int nst2 = (kt1 - kt0 + 1) & ~1;
   for (int s = 0; s < nst2; s += 2) {
     issue_stage(lds1);  // next stage's DMA in flight under this stage's MFMAs

@@ -30,6 +30,8 @@ LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch
     "fuse_interconv1": ("conv", 3, 1, 1, 162, 32, 4, 192, 256),
     "fuse_deconv0": ("deconv", 4, 2, 1, 162, 16, 4, 192, 256),
     "fuse_conv1_1": ("conv", 3, 1, 1, 64, 128, 4, 192, 256),
+    # long dispatches for counter / clock diagnostics
+    "conv3_1_b64": ("conv", 3, 1, 1, 256, 256, 64, 48, 64),
 }
 
 
@@ -83,7 +85,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--variants", default="0,16")
-    ap.add_argument("--layers", default=",".join(LAYERS))
+    ap.add_argument("--layers", default=",".join(k for k in LAYERS if not k.endswith("_b64")))
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--inner", type=int, default=5)
     ap.add_argument("--libs", default="", help="comma list of alternative builds of the library (tools/build_variant.sh); "
