@@ -77,6 +77,9 @@ class Engine:
         # consumer on the LDS-DMA conv kernel; small stems stay at multiples of 8
         line = 64 if self.act_code in (_hip.FN2_BF16, _hip.FN2_F16) else 32
         cs = (_round_up(c, line) if c > 32 else _round_up(c, 8)) if dtype is None else c
+        if dtype is None and not stem and line == 32 and 8 < c <= 32:
+            cs = 32  # one line: the 16-channel interconv0 output then feeds predict_flow0 as a head GEMM
+
         t = torch.zeros((n, h, w, cs), dtype=self.tdtype if dtype is None else dtype, device=self.device)
         assert name not in self.bufs, name
         self.bufs[name] = t
