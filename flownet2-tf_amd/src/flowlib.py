@@ -103,3 +103,106 @@ def flow_to_image(flow, maxflow=-1):
     img = compute_color(u / (maxrad + eps), v / (maxrad + eps))
     img[np.repeat(unknown[:, :, None], 3, axis=2)] = 0
     return np.uint8(img)
+
+
+# ---------------------------------------------------------------------------------------------------
+# MPI-Sintel error metrics used by Net.test_batch (reference src/flowlib.py: flow_error :379-430,
+# flow_error_mask :433-490, compute_all_metrics :215-375, get_metrics :182-212).  The reference indexes with
+# one-element lists of boolean arrays, which the NumPy it was written for read as plain boolean masks;
+# that reading is what is implemented here (tests/golden/metrics_golden.npz holds the reference's outputs).
+# Arithmetic stays in the dtype of the inputs (float32 for .flo data), like the reference's.
+# ---------------------------------------------------------------------------------------------------
+def _angular_and_epe(stu, stv, su, sv, sel, clamp_ge):
+    isu, isv = su[sel], sv[sel]
+    an = 1.0 / np.sqrt(isu ** 2 + isv ** 2 + 1)
+    istu, istv = stu[sel], stv[sel]
+    tn = 1.0 / np.sqrt(istu ** 2 + istv ** 2 + 1)
+    angle = (isu * an) * (istu * tn) + (isv * an) * (istv * tn) + (an * tn)
+    angle[(angle >= 1.0) if clamp_ge else (angle == 1.0)] = 0.999
+    with np.errstate(invalid="ignore"):
+        ang = np.arccos(angle)
+    mang = np.mean(ang) * 180 / np.pi
+    stdang = np.std(ang * 180 / np.pi)
+    epe = np.sqrt((stu - su) ** 2 + (stv - sv) ** 2)[sel]
+    return mang, stdang, np.mean(epe)
+
+
+def flow_error(tu, tv, u, v):
+    """(mean angular error [deg], its std, mean EPE) over pixels with non-zero known ground truth.  Like the
+    reference it zeroes the unknown pixels of its arguments IN PLACE and only clamps angle == 1.0 exactly, so
+    rounding above 1 gives NaN angular statistics (flowlib.py:398-430)."""
+    unknown = (abs(tu) > UNKNOWN_FLOW_THRESH) | (abs(tv) > UNKNOWN_FLOW_THRESH)
+    for a in (tu, tv, u, v):
+        a[unknown] = 0
+    sel = (np.absolute(tu) > 0.0) | (np.absolute(tv) > 0.0)
+    return _angular_and_epe(tu, tv, u, v, sel, clamp_ge=False)
+
+
+def flow_error_mask(tu, tv, u, v, mask=None, gt_value=False, bord=0):
+    """Same statistics over the pixels whose ground truth is known and whose `mask` entry differs from
+    `gt_value` (mask=None: every known pixel) (flowlib.py:433-490)."""
+    unknown = (abs(tu) > UNKNOWN_FLOW_THRESH) | (abs(tv) > UNKNOWN_FLOW_THRESH) | (mask == gt_value)
+    sel = (unknown < 1) & ((abs(tu) >= 0.0) | (abs(tv) >= 0.0))
+    return _angular_and_epe(tu, tv, u, v, sel, clamp_ge=True)
+
+
+def compute_all_metrics(est_flow, gt_flow, occ_mask=None, inv_mask=None):
+    """EPEall / EPEmat / EPEumat, S0-10 / S10-40 / S40+ and the angular statistics of MPI-Sintel for one
+    frame (flowlib.py:215-375).  Masks are uint8 images, 255 = occluded / invalid.  Returns (metrics dict,
+    not_occluded, s0_10_is_zero, s10_40_is_zero, s40plus_is_zero) -- the flags count frames in which a class is
+    empty, for averaging over a sequence."""
+    height, width, _ = gt_flow.shape
+    gx, gy = gt_flow[:, :, 0], gt_flow[:, :, 1]
+    ex, ey = est_flow[:, :, 0], est_flow[:, :, 1]
+    occ = (occ_mask == 255) if occ_mask is not None else np.full((height, width), False)
+    inv = (inv_mask == 255) if inv_mask is not None else np.full((height, width), False)
+    m = {}
+    m["mangall"], m["stdangall"], m["EPEall"] = flow_error_mask(gx, gy, ex, ey, inv, True)
+    if occ.size and np.unique(occ).shape[0] > 1:
+        m["mangmat"], m["stdangmat"], m["EPEmat"] = flow_error_mask(gx, gy, ex, ey, occ | inv, True)
+        m["mangumat"], m["stdangumat"], m["EPEumat"] = flow_error_mask(gx, gy, ex, ey, occ & ~inv, False)
+        not_occluded = 0
+    else:
+        m["mangmat"], m["stdangmat"], m["EPEmat"] = m["mangall"], m["stdangall"], m["EPEall"]
+        m["mangumat"] = m["stdangumat"] = m["EPEumat"] = 0
+        not_occluded = 1
+    speed = np.sqrt(gx ** 2 + gy ** 2)
+    cls = np.where(speed < 10, 0, np.where(speed <= 40, 1, 2))
+    empties = []
+    for c, key in ((0, "S0-10"), (1, "S10-40"), (2, "S40plus")):
+        if np.any(cls == c):
+            m[key] = flow_error_mask(gx, gy, ex, ey, (cls == c) & ~inv, False)[2]
+            empties.append(0)
+        else:
+            m[key] = 0
+            empties.append(1)
+    return (m, not_occluded) + tuple(empties)
+
+
+def get_metrics(metrics, average=False, flow_fname=None):
+    """The 13-line text block the reference logs per frame / per sequence (flowlib.py:182-212)."""
+    dash, line = "-" * 50, "_" * 50
+    if average:
+        title, name = "MPI-Sintel Flow Error Metrics (AVERAGE)", "For all files above"
+    else:
+        title, name = "MPI-Sintel Flow Error Metrics", flow_fname if flow_fname is not None else "Unknown filename"
+    row = "{:<5s}{:^15.4f}{:^15.4f}{:^15.4f}".format
+    head = "{:<5s}{:^15s}{:^15s}{:^15s}".format
+    rows = [line, "{:^50}".format(title), "{:^50}".format(name), line, head("Mask", "MANG", "STDANG", "MEPE"), dash,
+            row("(all)", metrics["mangall"], metrics["stdangall"], metrics["EPEall"]),
+            row("(mat)", metrics["mangmat"], metrics["stdangmat"], metrics["EPEmat"]),
+            row("(umt)", metrics["mangumat"], metrics["stdangumat"], metrics["EPEumat"]),
+            line, head("", "S0-10", "S10-40", "S40+"), dash,
+            row("(dis)", metrics["S0-10"], metrics["S10-40"], metrics["S40plus"])]
+    return "\n".join(rows) + "\n"
+
+
+def evaluate_flow(gt_flow, pred_flow):
+    """Mean EPE of two (H, W, 2) fields (flowlib.py:634-647)."""
+    return flow_error(gt_flow[:, :, 0].copy(), gt_flow[:, :, 1].copy(), pred_flow[:, :, 0].copy(),
+                      pred_flow[:, :, 1].copy())[2]
+
+
+def evaluate_flow_file(gt, pred):
+    """Mean EPE of two .flo files (flowlib.py:619-631)."""
+    return evaluate_flow(read_flow(gt), read_flow(pred))

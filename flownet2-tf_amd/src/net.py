@@ -1,5 +1,5 @@
 """Harness: the parts of /root/reference src/net.py that sit on the inference path
-(``Net.test`` :484-628, ``adapt_x`` :324-392, ``postproc_y_hat_test`` :463-473,
+(``Net.test`` :484-628, ``Net.test_batch`` :632-1000, ``adapt_x`` :324-392, ``postproc_y_hat_test`` :463-473,
 ``get_padded_image_size`` :301-309), re-expressed over the HIP engine.
 
 Deviations from the reference (its classic entry points are stale, SURVEY.md
@@ -18,7 +18,7 @@ import torch
 
 from . import weights as W
 from .engine import Engine
-from .flowlib import flow_to_image, read_flow, write_flow
+from .flowlib import compute_all_metrics, flow_to_image, get_metrics, read_flow, write_flow
 from .training_schedules import LONG_SCHEDULE
 
 
@@ -143,3 +143,128 @@ class Net(object):
             from .flowlib import endpoint_error
             print("{}: EPE all = {:.4f}".format(unique_name, endpoint_error(flow, gt)))
         return flow
+
+    # ---- inference over a list file (+ MPI-Sintel metrics) ---------------------------------------------
+    _METRIC_ORDER = ('mangall', 'stdangall', 'EPEall', 'mangmat', 'stdangmat', 'EPEmat', 'mangumat', 'stdangumat',
+                     'EPEumat', 'S0-10', 'S10-40', 'S40plus')
+
+    def test_batch(self, checkpoint, image_paths, out_path, input_type='image_pairs', save_image=True, save_flo=True,
+                   compute_metrics=True, accumulate_metrics=False, log_metrics2file=True, width=1024, height=436,
+                   new_par_folder=None, variational_refinement=False, batch_size=8):
+        """Inference on every line of the text file `image_paths` (net.py:632-1000): a line is
+        `img1 img2 [gt.flo [occ_mask.png [inv_mask.png]]]`.  Outputs per line as Net.test writes them; with a
+        ground truth, the MPI-Sintel metrics block goes to `<list name>_metrics.log` (or stdout), and
+        `accumulate_metrics` appends the sequence averages.  `width`/`height` are kept for signature
+        compatibility (the reference sizes its placeholders with them); frames are padded by their own size.
+        `batch_size` pairs of equal size go through the engine per launch (the reference feeds one pair per
+        sess.run).  The 'image_matches' input type belongs to FlowNetS_interp and is not built."""
+        if input_type != 'image_pairs':
+            raise NotImplementedError("test_batch: only input_type='image_pairs' (FlowNetS_interp is out of scope)")
+        if variational_refinement:
+            raise NotImplementedError("test_batch: variational refinement calls an external binary (out of scope)")
+        if self.weights is None:
+            self.load_weights(checkpoint)
+        with open(image_paths, 'r') as f:
+            lines = [ln.split() for ln in f.read().splitlines() if ln.strip()]
+        logfile = None
+        if log_metrics2file:
+            name = os.path.basename(image_paths).replace('.txt', '_metrics.log')
+            full = os.path.join(out_path, name) if new_par_folder is None else os.path.join(out_path, new_par_folder, name)
+            os.makedirs(os.path.dirname(full) or '.', exist_ok=True)
+            logfile = open(full, 'w')
+            if new_par_folder is not None:
+                import datetime
+                logfile.write("Today is {}\nOpening and logging experiment '{}'\n Written to file: '{}'\n".format(
+                    datetime.datetime.now().strftime('%d-%m-%y_%H-%M-%S'), new_par_folder, full))
+        rows, counts = [], np.zeros(4, np.int64)  # not occluded / empty S0-10 / S10-40 / S40+ frame counts
+        flows = []
+        try:
+            for start in range(0, len(lines), batch_size):
+                chunk = lines[start:start + batch_size]
+                for paths, flow in zip(chunk, self._infer_pairs(chunk, batch_size)):
+                    flows.append(flow)
+                    assert 2 <= len(paths) <= 5, 'expected: img1 img2 [gt_flow [occ_mask [inv_mask]]]'
+                    gt = read_flow(paths[2]) if len(paths) >= 3 else None
+                    occ = imread_gray(paths[3]) if len(paths) >= 4 and compute_metrics else None
+                    inv = imread_gray(paths[4]) if len(paths) >= 5 and compute_metrics else None
+                    max_flow = np.max(gt) if (compute_metrics and gt is not None) else -1
+                    parent = paths[0].split('/')[-2] if new_par_folder is None else new_par_folder
+                    unique_name = os.path.basename(paths[0])[:-4]
+                    out_dir = os.path.join(out_path, parent)
+                    if save_image or save_flo:
+                        os.makedirs(out_dir, exist_ok=True)
+                    if save_image:
+                        full = os.path.join(out_dir, unique_name + '_viz.png')
+                        imsave(full, flow_to_image(flow.copy()))
+                        imsave(full.replace('.png', '_norm_gt_max_motion.png'), flow_to_image(flow.copy(), maxflow=max_flow))
+                    if save_flo:
+                        write_flow(flow, os.path.join(out_dir, unique_name + '_flow.flo'))
+                    if compute_metrics and gt is not None:
+                        m, *flags = compute_all_metrics(flow, gt, occ_mask=occ, inv_mask=inv)
+                        text = get_metrics(m, flow_fname=unique_name)
+                        if accumulate_metrics:
+                            counts += np.array(flags)
+                            rows.append([m[k] for k in self._METRIC_ORDER])
+                        if logfile is not None:
+                            logfile.write(text)
+                        else:
+                            print(text)
+            if accumulate_metrics and rows:
+                avg = self._average_metrics(np.array(rows, np.float64).reshape(len(rows), -1), counts)
+                if logfile is not None:
+                    import datetime
+                    logfile.write('\n\nToday is: {}\nNow logging final averaged metrics \n\n'.format(
+                        datetime.datetime.now().strftime('%d-%m-%y_%H-%M-%S')))
+                    logfile.write(get_metrics(dict(zip(self._METRIC_ORDER, avg)), average=True))
+                self.last_average_metrics = dict(zip(self._METRIC_ORDER, avg))
+        finally:
+            if logfile is not None:
+                logfile.close()
+        return flows
+
+    def _infer_pairs(self, chunk, batch_size):
+        """Flows (cropped to each frame's size) of up to `batch_size` list lines, one engine launch per group of
+        equally sized frames; a short group is padded with zero pairs so that one engine serves the whole list."""
+        frames = [self.adapt_x(imread(p[0]), imread(p[1])) for p in chunk]
+        out = [None] * len(chunk)
+        by_shape = {}
+        for i, (a, _, _) in enumerate(frames):
+            by_shape.setdefault(a.shape, []).append(i)
+        for shape, idxs in by_shape.items():
+            n = batch_size
+            a = np.zeros((n,) + shape[1:], np.float32)
+            b = np.zeros_like(a)
+            for j, i in enumerate(idxs):
+                a[j], b[j] = frames[i][0][0], frames[i][1][0]
+            pred = self.engine(n, shape[1], shape[2])(a, b)['flow'].float().cpu().numpy()
+            for j, i in enumerate(idxs):
+                info = frames[i][2]
+                out[i] = self.postproc_y_hat_test(pred[j], (info[-3], info[-2], 2) if info is not None else None).copy()
+        return out
+
+    @staticmethod
+    def _average_metrics(table, counts):
+        """Sequence averages exactly as the reference forms them (net.py:958-984), quirks included: the divisor of
+        a column is (#entries != inf) + (#NaN entries); the unmatched columns are scaled by (1 - #frames without
+        occlusions) -- operator precedence at :971-972; the S0-10 column is rescaled by n / (n - #empty frames)
+        when some frame had no such pixels, while the S10-40 / S40+ rescalings sit behind inverted tests
+        (`if not count > 0`, :977-982) and therefore never change anything."""
+        n_cols = table.shape[-1]
+        avg = np.full(n_cols, np.inf)
+        divisor = np.zeros(n_cols)
+        for i in range(n_cols):
+            col = table[:, i]
+            divisor[i] = np.sum(col != np.inf) + np.sum(np.isnan(col))
+            avg[i] = np.sum(col[~np.isinf(col) & ~np.isnan(col)]) / divisor[i]
+        not_occluded, empty0, empty1, empty2 = (int(c) for c in counts)
+        if not_occluded > 0:
+            avg[6:9] = avg[6:9] * (1.0 - not_occluded)
+        if empty0 > 0:
+            avg[9] = avg[9] * (divisor[9] / (divisor[9] - empty0))
+        return avg
+
+
+def imread_gray(path):
+    """Mask image as the reference's imread returns it for single-channel PNGs: (H, W) uint8."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("L"))

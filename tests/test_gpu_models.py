@@ -142,3 +142,38 @@ def test_graph_replay_equals_eager():
     replay = eng(a, b)["flow"].clone()
     torch.cuda.synchronize()
     assert torch.equal(eager, replay)
+
+
+@pytest.mark.gpu
+def test_test_batch_writes_outputs_and_sintel_metrics(tmp_path, golden_dir):
+    """Net.test_batch (net.py:632-1000): list file of `img1 img2 gt`, batched through the engine; per-frame
+    flows equal the single-pair path, the metrics log holds one block per frame + the averages."""
+    from src import flowlib
+    from src.flownet_s.flownet_s import FlowNetS
+    from src.net import Mode
+    s = os.path.join(golden_dir, "samples")
+    seq = tmp_path / "alley_1"
+    seq.mkdir()
+    import shutil
+    for i, name in enumerate(("frame_0001", "frame_0002", "frame_0003")):
+        shutil.copy(os.path.join(s, "0img%d.ppm" % (i % 2)), seq / (name + ".ppm"))
+    lst = tmp_path / "sintel_clean.txt"
+    gt = os.path.join(s, "0flow.flo")
+    lst.write_text("%s %s %s\n%s %s %s\n" % (seq / "frame_0001.ppm", seq / "frame_0002.ppm", gt,
+                                             seq / "frame_0002.ppm", seq / "frame_0003.ppm", gt))
+    net = FlowNetS(mode=Mode.TEST, dtype="f16x2")
+    out = tmp_path / "out"
+    flows = net.test_batch(None, str(lst), str(out), accumulate_metrics=True, batch_size=2)
+    assert len(flows) == 2 and flows[0].shape == (384, 512, 2)
+    single = net.test(None, str(seq / "frame_0001.ppm"), str(seq / "frame_0002.ppm"), out_path=str(tmp_path / "one"),
+                      save_image=False, save_flo=False)
+    assert np.abs(flows[0] - single).max() < 1e-4
+    for name in ("frame_0001", "frame_0002"):
+        assert np.array_equal(flowlib.read_flow(str(out / "alley_1" / (name + "_flow.flo"))),
+                              flows[int(name[-1]) - 1])
+        assert (out / "alley_1" / (name + "_viz.png")).exists()
+        assert (out / "alley_1" / (name + "_viz_norm_gt_max_motion.png")).exists()
+    log = (out / "sintel_clean_metrics.log").read_text()
+    assert log.count("MPI-Sintel Flow Error Metrics") == 3 and "(AVERAGE)" in log and "frame_0002" in log
+    m, *_ = flowlib.compute_all_metrics(flows[0], flowlib.read_flow(gt))
+    assert ("%.4f" % m["EPEall"]) in log
