@@ -94,6 +94,11 @@ class Engine:
     def _v(self, buf, c=None, c0=0):
         return _hip.view(buf, c, c0, self._code(buf))
 
+    def _bias(self, scope, name, cout):
+        """Bias vector of a conv layer; a layer declared without one (biases_initializer=None) gets zeros."""
+        b = self.weights.get(f"{scope}/{name}/biases")
+        return W.to_device(b if b is not None else np.zeros(cout, np.float32), torch.float32, self.device)
+
     def _op(self, name, fn, *args, kernel=None):
         self.kernel_of.append(kernel if kernel is not None else fn.__name__.replace("fn2_", ""))
         self.ops.append((name, fn, args))
@@ -120,7 +125,7 @@ class Engine:
         tile, layout = plan.cout_tile, plan.layout
         if kind == "conv":
             packed, cin_pad, cout_pad, kpad = W.pack_conv(self.weights[wname], tile, plan.kstep_elems, cin_pad, layout)
-            bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
+            bias = self._bias(scope, name, cout)
         else:
             packed, cin_pad, cout_pad, kpad = W.pack_deconv(self.weights[wname], tile, plan.kstep_elems, cin_pad, layout)
             bias = None
@@ -190,7 +195,7 @@ class Engine:
                 k2 = int(math.floor(math.log2(1024.0 / wmax)))
                 packed, out_scale = packed * (2.0 ** k2), 2.0 ** (-k2)
         wdev = W.packed_to_device(packed, plan.wgt_dtype, self.device)
-        bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
+        bias = self._bias(scope, name, cout)
         if self._head_t is None:  # one scratch for every head: launches are ordered on one stream
             self._head_t = torch.zeros((self.N * self.H * self.W, 32), dtype=torch.float32, device=self.device)
         n, h, wd = pf.shape[0], pf.shape[1], pf.shape[2]
@@ -226,7 +231,7 @@ class Engine:
         assert plan.layout == 1, (scope, name)
         packed, cin_pad, cout_pad, kpad = W.pack_stem(self.weights[f"{scope}/{name}/weights"], cs, run,
                                                       plan.cout_tile, plan.layout)
-        bias = W.to_device(self.weights[f"{scope}/{name}/biases"], torch.float32, self.device)
+        bias = self._bias(scope, name, cout)
         out_scale = 1.0
         if plan.wgt_dtype == _hip.FN2_F16X2:
             k2 = int(math.floor(math.log2(1024.0 / float(abs(packed).max()))))
@@ -465,7 +470,7 @@ class Engine:
 
     def _build(self):
         m = self.model
-        if m == "FlowNetS":
+        if m in ("FlowNetS", "FlowNetS_interp"):  # interp: second "image" = [0.05*sparse_flow | matches]
             return self._net_s("FlowNetS", "S", self._pair_input("S", 3), 6)
         if m == "FlowNetC":
             return self._net_c("FlowNetC", "C")
@@ -485,6 +490,15 @@ class Engine:
             if tuple(t.shape) != tuple(dst.shape):
                 raise ValueError("input shape %s != engine shape %s" % (tuple(t.shape), tuple(dst.shape)))
             dst.copy_(t.to(dtype=torch.float32), non_blocking=True)
+
+    def set_inputs_interp(self, input_a, matches_a, sparse_flow):
+        """FlowNetS_interp input (flownet_s_interp.py:34-38): [image (3) | 0.05 * sparse_flow (2) | matches (1)]."""
+        dev = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(
+            device=self.device, dtype=torch.float32)
+        sf, m = dev(sparse_flow), dev(matches_a)
+        if m.ndim == 3:
+            m = m[..., None]
+        self.set_inputs(dev(input_a), torch.cat([sf * 0.05, m], dim=3))
 
     def launch(self):
         """Enqueue one forward pass on torch's current stream (no host sync)."""

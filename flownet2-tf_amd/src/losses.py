@@ -16,6 +16,53 @@ def average_endpoint_error(labels, predictions):
     return torch.sqrt((d * d).sum(dim=3)).sum() / n
 
 
+def average_endpoint_error_hfem(labels, predictions, add_hfem='', lambda_w=2., perc_hfem=50, edges=None):
+    """AEPE with optional hard-flow-example mining (src/utils.py:227-339).  add_hfem: '' plain AEPE; 'hard': only
+    the round(perc_hfem % of all pixels of the batch) largest EPE values count, weighted (1 + lambda_w), divided by
+    the batch size and scaled by #pixels / #hard pixels; 'edges': EPE map weighted by (1 + lambda_w * edges)."""
+    n = predictions.shape[0]
+    epe = torch.linalg.vector_norm(labels.float() - predictions.float(), dim=3, keepdim=True)
+    mode = (add_hfem or '').lower()
+    if mode == 'hard':
+        flat = epe.reshape(-1)
+        k = int(np.round(np.float32(perc_hfem / 100) * np.float32(flat.numel())))
+        hard = torch.topk(flat, k).values
+        return (1.0 + lambda_w) * hard.sum() / n * (flat.numel() / max(k, 1))
+    if mode == 'edges' and edges is not None:
+        return (epe + lambda_w * epe * _as_dev(edges, epe).float()).sum() / n
+    return epe.sum() / n
+
+
+def mean_endpoint_error(gt_flow, pred_flow):
+    """Mean over every pixel of the batch of ||gt - pred||_2 (src/utils.py:342-351)."""
+    return torch.linalg.vector_norm(gt_flow.float() - pred_flow.float(), dim=-1).mean()
+
+
+def multiscale_hfem_loss(targets, predictions, add_hard_flow_mining='', lambda_weight=2., hard_examples_perc=50,
+                         edges=None, weights=None, scope=None, l2=4e-4):
+    """FlowNetS_interp.loss (src/flownet_s_interp/flownet_s_interp.py:159-254): the five-scale weighted sum of
+    average_endpoint_error_hfem on 0.05 * targets (edges downsampled per scale with the same NaN-aware op), + the
+    slim L2 terms; returns (total loss, AEPE) where AEPE compares the SCALED targets with predictions['flow']
+    exactly as the reference does (:251)."""
+    p6 = predictions['predict_flow6']
+    t = _as_dev(targets, p6).to(device=p6.device, dtype=torch.float32) * 0.05
+    e = None if edges is None else _as_dev(edges, p6).to(device=p6.device, dtype=torch.float32)
+    losses = []
+    for lvl in (6, 5, 4, 3, 2):
+        p = predictions['predict_flow%d' % lvl]
+        size = [p.shape[1], p.shape[2]]
+        e_l = downsample(e, size) if (e is not None and add_hard_flow_mining) else e
+        losses.append(average_endpoint_error_hfem(downsample(t, size), p, add_hard_flow_mining, lambda_weight,
+                                                  hard_examples_perc, e_l))
+    total = sum(w * l for w, l in zip(LOSS_WEIGHTS, losses)) / 5.0
+    if weights is not None and scope is not None:
+        total = total + sum(0.5 * l2 * float(np.sum(np.square(np.asarray(w, np.float64))))
+                            for name, w in weights.items()
+                            if name.startswith(scope + "/") and name.endswith("/weights")
+                            and "deconv" not in name and "upsample_flow" not in name)
+    return total, mean_endpoint_error(t, predictions['flow'])
+
+
 def _as_dev(x, like):
     return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x), device=like.device)
 

@@ -106,18 +106,47 @@ class Net(object):
             a, b = np.pad(a, pad), np.pad(b, pad)
         return a.astype(np.float32), b.astype(np.float32), info
 
+    def adapt_x_matches(self, input_a, matches_a, sparse_flow, divisor=64):
+        """adapt_x for (image, match mask, sparse flow) (net.py:324-392): image and mask to [0,1] when their max
+        exceeds 1, mask gets its channel axis, all three batched and zero-padded to multiples of `divisor`."""
+        a = np.asarray(input_a)
+        a = a / 255.0 if a.max() > 1.0 else a.astype(np.float64)
+        m = np.asarray(matches_a)[..., np.newaxis]
+        m = m / 255.0 if m.max() > 1.0 else m.astype(np.float64)
+        sf = np.asarray(sparse_flow, np.float32)
+        assert m.shape[:2] == a.shape[:2] and m.shape[2] == 1, (
+            "Mask has invalid dimensions. Should be ({0}, {1}, 1) but are {2}".format(a.shape[0], a.shape[1], m.shape))
+        a, m, sf = a[None], m[None], sf[None]
+        h, w = a.shape[1:3]
+        nh, nw = self.get_padded_image_size(h, w, divisor)
+        info = None
+        if (nh, nw) != (h, w):
+            info = a.shape
+            pad = [(0, 0), (0, nh - h), (0, nw - w), (0, 0)]
+            a, m, sf = np.pad(a, pad), np.pad(m, pad), np.pad(sf, pad)
+        return a.astype(np.float32), m.astype(np.float32), sf.astype(np.float32), info
+
     def postproc_y_hat_test(self, pred_flows, adapt_info=None):
         if adapt_info is not None:
             pred_flows = pred_flows[0:adapt_info[-3], 0:adapt_info[-2], :]
         return pred_flows
 
     # ---- single-pair inference ----------------------------------------------------------------------
-    def test(self, checkpoint, input_a_path, input_b_path=None, out_path='./', save_image=True, save_flo=True,
-             compute_metrics=True, gt_flow=None, new_par_folder=None):
-        a, b, info = self.adapt_x(imread(input_a_path), imread(input_b_path))
+    def test(self, checkpoint, input_a_path, input_b_path=None, matches_a_path=None, sparse_flow_path=None,
+             out_path='./', input_type='image_pairs', save_image=True, save_flo=True, compute_metrics=True,
+             gt_flow=None, new_par_folder=None):
+        """net.py:484-628.  input_type 'image_matches' (FlowNetS_interp): first image + match mask + sparse flow."""
         if self.weights is None:
             self.load_weights(checkpoint)
-        preds = self.model({'input_a': a, 'input_b': b}, LONG_SCHEDULE, trainable=False)
+        if input_type == 'image_matches':
+            if matches_a_path is None or sparse_flow_path is None:
+                raise ValueError("input_type 'image_matches' needs matches_a_path and sparse_flow_path")
+            a, m, sf, info = self.adapt_x_matches(imread(input_a_path), imread_gray(matches_a_path),
+                                                  read_flow(sparse_flow_path))
+            preds = self.model({'input_a': a, 'matches_a': m, 'sparse_flow': sf}, LONG_SCHEDULE, trainable=False)
+        else:
+            a, b, info = self.adapt_x(imread(input_a_path), imread(input_b_path))
+            preds = self.model({'input_a': a, 'input_b': b}, LONG_SCHEDULE, trainable=False)
         flow = preds['flow'][0].float().cpu().numpy()
         y_info = (info[-3], info[-2], 2) if info is not None else None
         flow = self.postproc_y_hat_test(flow, y_info)

@@ -76,7 +76,7 @@ def fusion_layers():
 def model_scopes(model):
     """[(variable scope, layer table)] of a model; scope nesting as the reference's
     tf.variable_scope calls produce it (flownet_cs.py:16, flownet_css.py:16, flownet2.py:20)."""
-    if model == "FlowNetS":
+    if model in ("FlowNetS", "FlowNetS_interp"):  # the interpolation net keeps the scope (flownet_s_interp.py:23)
         return [("FlowNetS", flownet_s_layers(6))]
     if model == "FlowNetC":
         return [("FlowNetC", flownet_c_layers())]
@@ -97,4 +97,4 @@ def model_scopes(model):
     raise ValueError("unknown model %r" % model)
 
 
-MODELS = ("FlowNetS", "FlowNetC", "FlowNetSD", "FlowNetCS", "FlowNetCSS", "FlowNet2")
+MODELS = ("FlowNetS", "FlowNetC", "FlowNetSD", "FlowNetCS", "FlowNetCSS", "FlowNet2", "FlowNetS_interp")

@@ -12,13 +12,17 @@ import torch
 from . import netdefs
 
 
-def init_weights(model, seed=1234, flow_gain=0.25, bias_std=0.02):
+def init_weights(model, seed=1234, flow_gain=0.25, bias_std=0.02, head_biases=None):
     """Variance-scaling normal weights (the reference trains from
     slim.variance_scaling_initializer(), flownet_s.py:31): std = sqrt(2/fan_in) for
     LeakyReLU layers so activations stay O(1) through ~25 layers; linear layers
     sqrt(1/fan_in); flow heads scaled by ``flow_gain`` so that 20*predict_flow2
     spans several pixels (flow_warp then sees in- and out-of-range targets).
-    Small random biases exercise the bias path (the reference initialises them to 0)."""
+    Small random biases exercise the bias path (the reference initialises them to 0).
+    head_biases=False: no predict_flowN biases (FlowNetS_interp's default no_deconv_biases=True,
+    flownet_s_interp.py:12-14, :86-95)."""
+    if head_biases is None:
+        head_biases = model != "FlowNetS_interp"
     rng = np.random.default_rng(seed)
     w = {}
     for scope, layers in netdefs.model_scopes(model):
@@ -29,7 +33,9 @@ def init_weights(model, seed=1234, flow_gain=0.25, bias_std=0.02):
                 if name.startswith("predict_flow"):
                     std *= flow_gain
                 w[f"{scope}/{name}/weights"] = (rng.standard_normal((k, k, cin, cout)) * std).astype(np.float32)
-                w[f"{scope}/{name}/biases"] = (rng.standard_normal((cout,)) * bias_std).astype(np.float32)
+                b = (rng.standard_normal((cout,)) * bias_std).astype(np.float32)
+                if head_biases or not name.startswith("predict_flow"):
+                    w[f"{scope}/{name}/biases"] = b
             else:
                 fan_in = 4 * cin  # each output pixel of a k4 s2 transposed conv sees 2x2 taps
                 std = np.sqrt((2.0 if act else 1.0) / fan_in)

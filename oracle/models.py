@@ -24,7 +24,7 @@ class _Scope:
         # slim.conv2d under the arg_scope of flownet_s.py:26-37: bias present,
         # LeakyReLU unless activation_fn=None
         w = self.w[f"{self.s}/{name}/weights"]
-        b = self.w[f"{self.s}/{name}/biases"]
+        b = self.w.get(f"{self.s}/{name}/biases")  # absent: biases_initializer=None (flownet_s_interp.py:86-95)
         return nn.conv2d(x, w, b, stride=stride, padding=padding,
                          activation=nn.leaky_relu if act else None)
 
@@ -80,6 +80,17 @@ def flownet_s(weights, inputs, scope="FlowNetS"):
     c6_1 = sc.conv(sc.conv(c5_1, "conv6", 2), "conv6_1")
     preds = _refine(sc, (c6_1, c5_1, c4_1, c3_1, c2))
     return _finish(preds, H, W, 20.0)  # :107-111
+
+
+def flownet_s_interp(weights, inputs, scope="FlowNetS"):
+    """FlowNetS_interp.model (flownet_s_interp/flownet_s_interp.py:21-156): the FlowNetS tower on
+    [input_a | 0.05 * sparse_flow | matches_a] (:34-38), variable scope 'FlowNetS' (:23); with the class default
+    no_deconv_biases=True the predict_flow layers have no biases (:86-95)."""
+    m = np.asarray(inputs["matches_a"], F64)
+    if m.ndim == 3:
+        m = m[..., None]
+    second = np.concatenate([np.asarray(inputs["sparse_flow"], F64) * 0.05, m], axis=3)
+    return flownet_s(weights, {"input_a": inputs["input_a"], "input_b": second}, scope)
 
 
 def flownet_c(weights, inputs, scope="FlowNetC"):
@@ -176,7 +187,8 @@ def flownet2(weights, inputs, scope="FlowNet2"):
 
 
 MODELS = {"FlowNetS": flownet_s, "FlowNetC": flownet_c, "FlowNetSD": flownet_sd,
-          "FlowNetCS": flownet_cs, "FlowNetCSS": flownet_css, "FlowNet2": flownet2}
+          "FlowNetCS": flownet_cs, "FlowNetCSS": flownet_css, "FlowNet2": flownet2,
+          "FlowNetS_interp": flownet_s_interp}
 
 
 # ----------------------------------------------------------------------------
@@ -187,6 +199,31 @@ def average_endpoint_error(labels, predictions):
     the batch size only."""
     d = np.asarray(predictions, F64) - np.asarray(labels, F64)
     return float(np.sqrt(np.sum(d * d, axis=3)).sum() / d.shape[0])
+
+
+def average_endpoint_error_hfem(labels, predictions, add_hfem="", lambda_w=2.0, perc_hfem=50, edges=None):
+    """utils.py:227-339.  '' -> plain AEPE (sum of per-pixel EPE / batch).  'hard': the top round(perc/100 * #pixels)
+    EPE values (tf.nn.top_k over the whole flattened batch, :268-275) summed with weight (1 + lambda), divided by
+    the batch size and multiplied by #pixels / #hard pixels (:305-312).  'edges' (with an edge map in [0,1], same
+    N x H x W x 1 shape): sum of epe * (1 + lambda * edges) / batch (:315-324).  Anything else: plain AEPE."""
+    d = np.asarray(labels, F64) - np.asarray(predictions, F64)
+    epe = np.sqrt(np.sum(d * d, axis=3, keepdims=True))
+    n = d.shape[0]
+    mode = (add_hfem or "").lower()
+    if mode == "hard":
+        flat = epe.reshape(-1)
+        k = int(np.round(np.float32(perc_hfem / 100) * np.float32(flat.size)))  # tf.round: half to even
+        hard = np.sort(flat)[::-1][:k]
+        return float((1.0 + lambda_w) * hard.sum() / n * (flat.size / max(k, 1)))
+    if mode == "edges" and edges is not None:
+        return float((epe + lambda_w * epe * np.asarray(edges, F64)).sum() / n)
+    return float(epe.sum() / n)
+
+
+def mean_endpoint_error(gt_flow, pred_flow):
+    """utils.py:342-355: mean over all pixels and samples of the per-pixel L2 norm."""
+    d = np.asarray(gt_flow, F64) - np.asarray(pred_flow, F64)
+    return float(np.sqrt(np.sum(d * d, axis=3)).mean())
 
 
 def multiscale_loss(gt_flow, preds, weights=None, scope="FlowNetS", l2=4e-4, gt_scale=0.05):

@@ -177,3 +177,60 @@ def test_test_batch_writes_outputs_and_sintel_metrics(tmp_path, golden_dir):
     assert log.count("MPI-Sintel Flow Error Metrics") == 3 and "(AVERAGE)" in log and "frame_0002" in log
     m, *_ = flowlib.compute_all_metrics(flows[0], flowlib.read_flow(gt))
     assert ("%.4f" % m["EPEall"]) in log
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_flownet_s_interp_matches_oracle(dtype):
+    """FlowNetS_interp (flownet_s_interp.py:21-156): image + sparse flow + match mask -> dense flow."""
+    from src import weights as W
+    from src.flownet_s_interp.flownet_s_interp import FlowNetS_interp
+    from src.net import Mode
+    rng = np.random.default_rng(9)
+    H, Wd = 128, 192  # predict_flow6 must be at least 2x2 for the loss downsample
+    a = rng.random((2, H, Wd, 3), dtype=np.float32)
+    m = (rng.random((2, H, Wd, 1)) > 0.9).astype(np.float32)
+    sf = (rng.standard_normal((2, H, Wd, 2)) * 8).astype(np.float32) * m
+    net = FlowNetS_interp(mode=Mode.TEST, dtype=dtype)
+    wts = net.load_weights(None, seed=21)
+    inputs = {"input_a": a, "matches_a": m, "sparse_flow": sf}
+    got = net.model(inputs)
+    want = refm.flownet_s_interp(wts, inputs)
+    for k in ("predict_flow6", "predict_flow2", "flow"):
+        g = got[k].float().cpu().numpy()
+        assert refm.average_endpoint_error(want[k], g) / (g.shape[1] * g.shape[2]) < 1e-3
+    assert set(net.model(inputs, is_training=False)) == {"flow"}
+    # loss: five-scale HFEM ('hard') + L2 against the NumPy restatement
+    gt = (rng.standard_normal((2, H, Wd, 2)) * 5).astype(np.float32)
+    total, aepe = net.loss(gt, got, add_hard_flow_mining="hard", lambda_weight=2.0, hard_examples_perc=50)
+    from oracle import ops as refops
+    t = gt * np.float32(0.05)
+    ref = 0.0
+    for lvl, wgt in zip((6, 5, 4, 3, 2), (0.32, 0.08, 0.02, 0.01, 0.005)):
+        p = want["predict_flow%d" % lvl]
+        ref += wgt * refm.average_endpoint_error_hfem(refops.downsample(t, p.shape[1:3]), p, "hard", 2.0, 50)
+    ref = ref / 5.0 + sum(0.5 * 4e-4 * float(np.sum(np.square(v.astype(np.float64)))) for k, v in wts.items()
+                          if k.endswith("/weights") and "deconv" not in k and "upsample_flow" not in k)
+    assert float(total) == pytest.approx(ref, rel=2e-4)
+    assert float(aepe) == pytest.approx(refm.mean_endpoint_error(t, want["flow"]), rel=1e-4)
+
+
+@pytest.mark.gpu
+def test_interp_cli_path_writes_flow(tmp_path, golden_dir):
+    from PIL import Image
+    from src import flowlib
+    from src.flownet_s_interp.flownet_s_interp import FlowNetS_interp
+    from src.net import Mode
+    s = os.path.join(golden_dir, "samples")
+    gt = flowlib.read_flow(os.path.join(s, "0flow.flo"))
+    mask = (np.random.default_rng(2).random(gt.shape[:2]) > 0.95)
+    Image.fromarray((mask * 255).astype(np.uint8)).save(tmp_path / "mask.png")
+    flowlib.write_flow(gt * mask[..., None], str(tmp_path / "sparse.flo"))
+    net = FlowNetS_interp(mode=Mode.TEST, dtype="f16x2")
+    flow = net.test(None, os.path.join(s, "0img0.ppm"), matches_a_path=str(tmp_path / "mask.png"),
+                    sparse_flow_path=str(tmp_path / "sparse.flo"), input_type="image_matches",
+                    out_path=str(tmp_path), gt_flow=os.path.join(s, "0flow.flo"))
+    assert flow.shape == (384, 512, 2) and np.isfinite(flow).all()
+    assert np.array_equal(flowlib.read_flow(str(tmp_path / "samples" / "0img0_flow.flo")), flow)
+    with pytest.raises(ValueError):
+        net.test(None, os.path.join(s, "0img0.ppm"), input_type="image_matches", out_path=str(tmp_path))

@@ -193,3 +193,36 @@ def test_cli_argument_checks(tmp_path):
     r = subprocess.run([sys.executable, "-m", "src.flownet2.test", "--input_a", os.path.join(ROOT, "bench.py")],
                        cwd=pkg, capture_output=True, text=True)
     assert r.returncode != 0 and "required" in r.stderr
+
+
+def test_hfem_losses_match_oracle_on_cpu_tensors():
+    """src.losses.average_endpoint_error_hfem / mean_endpoint_error are plain torch: check them on CPU tensors
+    against the NumPy restatement of utils.py:227-351."""
+    import torch
+    from oracle import models as refm
+    from src import losses
+    rng = np.random.default_rng(5)
+    lab, pred = rng.standard_normal((3, 6, 7, 2)).astype(np.float32), rng.standard_normal((3, 6, 7, 2)).astype(np.float32)
+    edges = rng.random((3, 6, 7, 1)).astype(np.float32)
+    tl, tp, te = torch.from_numpy(lab), torch.from_numpy(pred), torch.from_numpy(edges)
+    for mode, kw in (("", {}), ("hard", {}), ("hard", {"perc_hfem": 33, "lambda_w": 1.0}), ("edges", {"edges": edges}),
+                     ("edges", {}), ("other", {})):
+        tkw = {k: (te if k == "edges" else v) for k, v in kw.items()}
+        got = float(losses.average_endpoint_error_hfem(tl, tp, mode, **tkw))
+        assert got == pytest.approx(refm.average_endpoint_error_hfem(lab, pred, mode, **kw), rel=1e-5)
+    assert float(losses.mean_endpoint_error(tl, tp)) == pytest.approx(refm.mean_endpoint_error(lab, pred), rel=1e-5)
+
+
+def test_interp_weights_and_class_surface():
+    from src import weights as W
+    from src.flownet_s_interp.flownet_s_interp import FlowNetS_interp
+    w = W.init_weights("FlowNetS_interp", 3)
+    assert "FlowNetS/conv1/weights" in w and w["FlowNetS/conv1/weights"].shape == (7, 7, 6, 64)
+    assert not any("/predict_flow" in k and k.endswith("/biases") for k in w)   # no_deconv_biases default
+    net = FlowNetS_interp()
+    assert net.scope == "FlowNetS" and net.no_deconv_biases is True
+    a, m, sf, info = net.adapt_x_matches(np.full((436, 1024, 3), 200, np.uint8), np.full((436, 1024), 255, np.uint8),
+                                         np.ones((436, 1024, 2), np.float32))
+    assert a.shape == (1, 448, 1024, 3) and m.shape == (1, 448, 1024, 1) and sf.shape == (1, 448, 1024, 2)
+    assert info == (1, 436, 1024, 3) and m.max() == 1.0 and a.max() == pytest.approx(200 / 255.0)
+    assert sf[0, 440].max() == 0.0
