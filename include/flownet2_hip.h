@@ -249,6 +249,19 @@ typedef struct {
 } fn2_bwdw_desc;
 int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream);
 
+/* ---------------------------------------------------------------- training-input augmentation
+ * The reference's preprocessing plugin (src/ops/preprocessing/preprocessing.cc:24-95).  The random coefficients
+ * and their 2x3 matrices are made on the host (as the op does, HostMemory transforms); these are the per-pixel
+ * passes.  All pointers are device pointers; transforms / chromatic are [n][6] fp32. */
+/* DataAugmentation (kernels/data_augmentation.cc:30-150): out[n,y,x,:] = bilinear(src[n], T_n(x,y)), position
+ * clamped to [0, size-1.05]; chromatic != NULL (c == 3): colour gains, brightness compensation, gamma,
+ * brightness, contrast, clamp to [0,1]; chromatic[n] = (gamma, brightness, contrast, color1..3). */
+int fn2_augment_f32(const float* src, const float* transforms, const float* chromatic, float* out, int n, int src_h,
+                    int src_w, int c, int out_h, int out_w, void* stream);
+/* FlowAugmentation (kernels/flow_augmentation.cc:19-66): out = T_b^-1(T_a(x,y) + flow[round(T_a(x,y))]) - (x,y). */
+int fn2_flow_augmentation_f32(const float* flows, const float* transforms_from_a, const float* inv_transforms_from_b,
+                              float* out, int n, int src_h, int src_w, int out_h, int out_w, void* stream);
+
 /* ---------------------------------------------------------------- launch-graph helpers (hipGraph) */
 int fn2_capture_begin(void* stream);
 int fn2_capture_end(void* stream, void** graph_exec);
