@@ -48,7 +48,15 @@ __global__ void __launch_bounds__(256) corr2_kernel(const CorrArgs p, const int 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xb = blockIdx.x * 64, y = blockIdx.y, n = blockIdx.z;
+  // XCD-aware order (see conv2.hip): workgroups go round-robin over the 8 XCDs by linear id, so with the plain
+  // (x, y, n) mapping the 21 output rows that share a displaced B row run on 8 different L2s.  Each XCD gets a
+  // contiguous band of (n, y, x-block) instead: for batch 8 exactly one image, whose B features (3 MB in split
+  // fp16) stay in that XCD's 4 MB L2 across the 21 re-reads.
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int NT = gx * gy * (int)gridDim.z, L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int xcd = L & 7, chunk = NT >> 3, rem = NT & 7;
+  const int Lp = xcd * chunk + min(xcd, rem) + (L >> 3);
+  const int xb = (Lp % gx) * 64, y = (Lp / gx) % gy, n = Lp / (gx * gy);
   OutT* out = reinterpret_cast<OutT*>(p.out);
   const int fi = lane & 15, fg = lane >> 4;
 

@@ -281,6 +281,98 @@ __global__ void __launch_bounds__(256) downsample_kernel(const float* __restrict
   }
 }
 
+// Separable form of the same op, one block per output ROW (n, dy).  The tap weight is a product wx(xo) * wy(yo)
+// and the three sums (value, weight, NaN weight) are linear in it, so
+//   sum_{yo,xo} wy wx f(xo,yo) = sum_yo wy ( sum_xo wx f(xo,yo) ).
+// Phase 1 writes the horizontal sums of every window row to LDS ([row][dx][c] x 3 floats), phase 2 combines them
+// vertically.  O(window) instead of O(window^2) work per output; only the summation ORDER differs from the
+// reference's serial loop (fp32 rounding, ~1e-7 relative).  Used when the LDS image fits (host check).
+// Block per output row (n, dy), a thread per (window row, dx, c) walks its few taps.
+__global__ void __launch_bounds__(256) downsample_sep_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int N, int Hin, int Win, int C, int oh, int ow,
+                                                             float wscale, float hscale, int wr, int hr) {
+  extern __shared__ float rows[];  // [wh][ow*C][3]
+  const int dy = blockIdx.x % oh, n = blockIdx.x / oh;
+  const float srcy = ((float)dy / (float)(oh - 1)) * (float)(Hin - 1);
+  const int iy = (int)roundf(srcy);
+  const int wh = 2 * hr + 1, ww = 2 * wr + 1, rowlen = ow * C;
+  for (int item = threadIdx.x; item < wh * rowlen; item += blockDim.x) {
+    const int r = item / rowlen, e = item - r * rowlen;
+    const int dx = e / C, c = e - dx * C;
+    const int yo = iy - hr + r;
+    float av = 0.f, aw = 0.f, an = 0.f;
+    if (yo >= 0 && yo < Hin) {
+      const float srcx = ((float)dx / (float)(ow - 1)) * (float)(Win - 1);
+      const int ix = (int)roundf(srcx);
+      const float* p = in + ((long)n * Hin + yo) * Win * C + c;
+      for (int k = 0; k < ww; ++k) {
+        const int xo = ix - wr + k;
+        if (xo < 0 || xo >= Win) continue;
+        const float wgt = fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale);
+        const float sv = p[(long)xo * C];
+        if (sv != sv) an += wgt; else { av += sv * wgt; aw += wgt; }
+      }
+    }
+    rows[item * 3 + 0] = av; rows[item * 3 + 1] = aw; rows[item * 3 + 2] = an;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < rowlen; e += blockDim.x) {
+    float av = 0.f, aw = 0.f, an = 0.f;
+    for (int r = 0; r < wh; ++r) {
+      const int yo = iy - hr + r;
+      if (yo < 0 || yo >= Hin) continue;
+      const float wy = fmaxf(0.f, 1.f - fabsf((float)yo - srcy) / hscale);
+      const float* q = rows + ((long)r * rowlen + e) * 3;
+      av += wy * q[0]; aw += wy * q[1]; an += wy * q[2];
+    }
+    out[((long)n * oh + dy) * rowlen + e] = (an / aw > 0.5f) ? __int_as_float(0x7fffffff) : av / aw;
+  }
+}
+
+// Wide windows (>= 32 taps per row, i.e. the coarse loss scales: few outputs, thousands of taps each): a block of
+// 16 wavefronts per output PIXEL.  A wavefront per window row, lanes stride the taps of the row (coalesced), all
+// C <= 4 channels per tap, shuffle reduction, vertical weights applied per row, then one LDS reduction over rows.
+__global__ void __launch_bounds__(1024) downsample_wide_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int N, int Hin, int Win, int C, int oh, int ow,
+                                                               float wscale, float hscale, int wr, int hr) {
+  __shared__ float part[16][4][3];
+  const int dx = blockIdx.x % ow, dy = (blockIdx.x / ow) % oh, n = blockIdx.x / ow / oh;
+  const float srcx = ((float)dx / (float)(ow - 1)) * (float)(Win - 1);
+  const float srcy = ((float)dy / (float)(oh - 1)) * (float)(Hin - 1);
+  const int ix = (int)roundf(srcx), iy = (int)roundf(srcy);
+  const int wh = 2 * hr + 1, ww = 2 * wr + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  float av[4] = {0, 0, 0, 0}, aw[4] = {0, 0, 0, 0}, an[4] = {0, 0, 0, 0};
+  for (int r = wave; r < wh; r += nwave) {
+    const int yo = iy - hr + r;
+    if (yo < 0 || yo >= Hin) continue;
+    const float wy = fmaxf(0.f, 1.f - fabsf((float)yo - srcy) / hscale);
+    const float* p = in + ((long)n * Hin + yo) * Win * C;
+    for (int k = lane; k < ww; k += 64) {
+      const int xo = ix - wr + k;
+      if (xo < 0 || xo >= Win) continue;
+      const float wgt = wy * fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) {
+          const float sv = p[(long)xo * C + c];
+          if (sv != sv) an[c] += wgt; else { av[c] += sv * wgt; aw[c] += wgt; }
+        }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float a = wave_sum(av[c]), b = wave_sum(aw[c]), d = wave_sum(an[c]);
+    if (lane == 0) { part[wave][c][0] = a; part[wave][c][1] = b; part[wave][c][2] = d; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float a = 0.f, b = 0.f, d = 0.f;
+    for (int w = 0; w < nwave; ++w) { a += part[w][threadIdx.x][0]; b += part[w][threadIdx.x][1]; d += part[w][threadIdx.x][2]; }
+    out[(long)blockIdx.x * C + threadIdx.x] = (d / b > 0.5f) ? __int_as_float(0x7fffffff) : a / b;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // resize_bilinear(align_corners=True) of scale*in (flownet_s.py:107-111)
 // ---------------------------------------------------------------------------
@@ -427,8 +519,16 @@ int fn2_downsample_f32(const float* in, float* out, int n, int in_h, int in_w, i
   FN2_REQUIRE(out_h > 1 && out_w > 1, "downsample: output size 1 divides by zero in the reference kernel");
   const int wr = (int)ceilf(wscale), hr = (int)ceilf(hscale);
   const long nout = (long)n * out_h * out_w;
-  hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(nout * 64, 256)), dim3(256), 0, (hipStream_t)stream, in,
-                     out, n, in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr);
+  const size_t lds = (size_t)(2 * hr + 1) * out_w * c * 3 * sizeof(float);
+  if (2 * wr + 1 >= 32 && c <= 4 && nout < (1L << 30))
+    hipLaunchKernelGGL(downsample_wide_kernel, dim3((unsigned)nout), dim3(1024), 0, (hipStream_t)stream, in, out, n, in_h,
+                       in_w, c, out_h, out_w, wscale, hscale, wr, hr);
+  else if (lds <= 64 * 1024 && (long)n * out_h < (1L << 30))
+    hipLaunchKernelGGL(downsample_sep_kernel, dim3(n * out_h), dim3(256), lds, (hipStream_t)stream, in, out, n,
+                       in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr);
+  else
+    hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(nout * 64, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, n, in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr);
   FN2_CHECK_LAUNCH("downsample");
   return FN2_OK;
 }
