@@ -508,6 +508,38 @@ __global__ void __launch_bounds__(256) pack_image_kernel(const float* __restrict
   }
 }
 
+// Space-to-depth image packing for a stride-2 stem: out[n, sy, sx, (py*2+px)*4 + c] = padded_img[2sy+py, 2sx+px, c]
+// (c < 3, 4th channel 0), padded_img = img with a zero border of `pad` pixels.  A k x k stride-2 convolution
+// on the image is then a ceil(k/2) x ceil(k/2) stride-1 convolution on these 16-channel super-pixels: a kernel
+// row is a run of 4 x 16 channels = whole 128-byte lines with NO padding taps (7x7x3: 8 stages instead of 14).
+// One lane per super-pixel, border super-pixels included (the buffer needs no pre-zeroing).
+template <typename OutT>
+__global__ void __launch_bounds__(256) pack_image_s2d_kernel(const float* __restrict__ img, OutT* __restrict__ out,
+                                                             int n, int h, int w, int n0, int pad, int out_cs) {
+  const int hs = (h + 2 * pad) / 2, ws = (w + 2 * pad) / 2;
+  const long total = (long)n * hs * ws;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int sx = (int)(i % ws), sy = (int)((i / ws) % hs), nn = (int)(i / ws / hs);
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 2 * sy + (q >> 1) - pad, x = 2 * sx + (q & 1) - pad;
+      const bool ok = y >= 0 && y < h && x >= 0 && x < w;
+      const float* p = img + (((long)nn * h + (ok ? y : 0)) * w + (ok ? x : 0)) * 3;
+      v[q * 4 + 0] = ok ? p[0] : 0.f; v[q * 4 + 1] = ok ? p[1] : 0.f; v[q * 4 + 2] = ok ? p[2] : 0.f; v[q * 4 + 3] = 0.f;
+    }
+    OutT* d = out + (((size_t)(n0 + nn) * hs + sy) * ws + sx) * out_cs;
+    if constexpr (is_x2<OutT>::value) {
+      uint4* qd = reinterpret_cast<uint4*>(d);
+      split8(v, qd[0], qd[1]);
+      split8(v + 8, qd[2], qd[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) store_vec<OutT, 4>(d + 4 * k, v + 4 * k);
+    }
+  }
+}
+
 static inline int grid_for(long work_items, int block) {
   long g = (work_items + block - 1) / block;
   if (g > 256L * 16) g = 256L * 16;
@@ -825,6 +857,29 @@ int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, int pad
   if (rc) return rc;
   FN2_REQUIRE(out->c == 6, "pack_pair: output view must have 6 channels");
   return pack_imgs<2>(a, b, out, out->n, 0, pad, stream);
+}
+
+int fn2_pack_image_s2d(const float* img, int n_img, int h, int w, const fn2_tensor* out, int n0, int pad, void* stream) {
+  FN2_REQUIRE(img, "pack_image_s2d: null pointer");
+  int rc = check_view(out, "pack_image_s2d output");
+  if (rc) return rc;
+  FN2_REQUIRE(pad >= 0 && (h + 2 * pad) % 2 == 0 && (w + 2 * pad) % 2 == 0, "pack_image_s2d: padded size must be even");
+  FN2_REQUIRE(out->h == (h + 2 * pad) / 2 && out->w == (w + 2 * pad) / 2 && out->c == 16 && out->c0 == 0 && out->cs == 16,
+              "pack_image_s2d: output must be the whole [n, (h+2pad)/2, (w+2pad)/2, 16] buffer");
+  FN2_REQUIRE(n_img >= 1 && n0 >= 0 && n0 + n_img <= out->n, "pack_image_s2d: rows [n0, n0+n_img) outside the buffer");
+  const long total = (long)n_img * out->h * out->w;
+  const dim3 g(grid_for(total, 256)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (out->dtype == FN2_F32)
+    hipLaunchKernelGGL(pack_image_s2d_kernel<float>, g, b, 0, s, img, (float*)out->data, n_img, h, w, n0, pad, out->cs);
+  else if (out->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(pack_image_s2d_kernel<x2_t>, g, b, 0, s, img, (x2_t*)out->data, n_img, h, w, n0, pad, out->cs);
+  else if (out->dtype == FN2_BF16)
+    hipLaunchKernelGGL(pack_image_s2d_kernel<bf16_t>, g, b, 0, s, img, (bf16_t*)out->data, n_img, h, w, n0, pad, out->cs);
+  else
+    hipLaunchKernelGGL(pack_image_s2d_kernel<f16_t>, g, b, 0, s, img, (f16_t*)out->data, n_img, h, w, n0, pad, out->cs);
+  FN2_CHECK_LAUNCH("pack_image_s2d");
+  return FN2_OK;
 }
 
 int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, int pad, void* stream) {

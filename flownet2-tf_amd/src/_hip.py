@@ -66,6 +66,7 @@ PROTOTYPES = {
     "fn2_upsample_flow": (_i, [_p, _p, _tp, _i, _i, _i, _p]),
     "fn2_pack_pair": (_i, [_p, _p, _tp, _i, _p]),
     "fn2_pack_image": (_i, [_p, _i, _tp, _i, _i, _p]),
+    "fn2_pack_image_s2d": (_i, [_p, _i, _i, _i, _tp, _i, _i, _p]),
     "fn2_correlation_fused": (_i, [_tp, _tp, _tp, _i, _i, _i, _p]),
     "fn2_stack_input": (_i, [_p, _p, _p, _tp, _i, _p]),
     "fn2_fusion_input": (_i, [_p, _p, _p, _p, _tp, _i, _p]),

@@ -217,20 +217,31 @@ class Engine:
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
         return True
 
-    def _conv_stem(self, scope, spec, sbuf, dst):
+    def _conv_stem(self, scope, spec, sbuf, dst, s2d=False):
         """First layer of a network on its pre-padded few-channel input: kind-2 row-run convolution
-        (the kw taps x cs channels of a kernel row are one contiguous run of whole 128-byte lines)."""
+        (the kw taps x cs channels of a kernel row are one contiguous run of whole 128-byte lines).
+        s2d: the input buffer holds 2x2 space-to-depth super-pixels (fn2_pack_image_s2d) and the k x k stride-2
+        filter runs as a ceil(k/2)^2 stride-1 filter with re-indexed weights."""
         name, kind, k, stride, pad, cin, cout, act = spec
         dbuf, dc0, dc = dst
         assert kind == "conv" and dc == cout
+        k_alg, cin_alg = k, cin
+        w_hwio = self.weights[f"{scope}/{name}/weights"]
+        if s2d:
+            assert stride == 2 and cin == 3 and sbuf.shape[3] == 16
+            k2 = (k + 1) // 2
+            w = np.zeros((k2, k2, 16, cout), np.float32)
+            for ky in range(k):
+                for kx in range(k):
+                    w[ky // 2, kx // 2, ((ky & 1) * 2 + (kx & 1)) * 4:((ky & 1) * 2 + (kx & 1)) * 4 + 3] = w_hwio[ky, kx]
+            w_hwio, k, stride, cin = w, k2, 1, 16
         cs = sbuf.shape[3]
         in_code = self._code(sbuf)
         esz = 2 if in_code in (_hip.FN2_BF16, _hip.FN2_F16) else 4
         run = _round_up(k * cs, 128 // esz)
         plan = _hip.conv_plan(in_code, run, cout)
         assert plan.layout == 1, (scope, name)
-        packed, cin_pad, cout_pad, kpad = W.pack_stem(self.weights[f"{scope}/{name}/weights"], cs, run,
-                                                      plan.cout_tile, plan.layout)
+        packed, cin_pad, cout_pad, kpad = W.pack_stem(w_hwio, cs, run, plan.cout_tile, plan.layout)
         bias = self._bias(scope, name, cout)
         out_scale = 1.0
         if plan.wgt_dtype == _hip.FN2_F16X2:
@@ -259,7 +270,7 @@ class Engine:
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
                  kernel=f"conv_igemm2_kernel<{tn}, {tn}, {_TILE_ARGS[plan.cout_tile]}>")
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
-        self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * k * k * cin * cout))
+        self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * k_alg * k_alg * cin_alg * cout))
 
     def _upflow(self, scope, name, src_f32, dst):
         dbuf, dc0, dc = dst
@@ -356,13 +367,15 @@ class Engine:
         N, H, W_ = self.N, self.H, self.W
         L = {s[0]: s for s in netdefs.flownet_c_layers()}
         cats = self._alloc_cats(tag, N)
-        x2 = self._buf(f"{tag}/images", 2 * N, H + 6, W_ + 6, 3, stem=True)  # pad(.., 3) baked in, :30-34
-        v = self._v(x2, 3, 0)
+        # both towers' images as 2x2 space-to-depth super-pixels with pad(.., 3) baked in (:30-34): the 7x7
+        # stride-2 conv1 then runs as a 4x4 stride-1 row-run convolution over 16-channel super-pixels
+        x2 = self._buf(f"{tag}/images", 2 * N, (H + 6) // 2, (W_ + 6) // 2, 16, stem=True)
+        v = self._v(x2, 16, 0)
         self.keep.append(v)
-        self._op(f"{tag}/pack_a", self.lib.fn2_pack_image, _hip.ptr(self.in_a), N, C.byref(v), 0, 3)
-        self._op(f"{tag}/pack_b", self.lib.fn2_pack_image, _hip.ptr(self.in_b), N, C.byref(v), N, 3)
+        self._op(f"{tag}/pack_a", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_a), N, H, W_, C.byref(v), 0, 3)
+        self._op(f"{tag}/pack_b", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_b), N, H, W_, C.byref(v), N, 3)
         c1 = self._buf(f"{tag}/conv1", 2 * N, H // 2, W_ // 2, 64)
-        self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64))
+        self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64), s2d=True)
         c2b = self._buf(f"{tag}/conv_b_2", N, H // 4, W_ // 4, 128)
         self._conv(scope, L["conv2"], (c1[:N], 0, 64), (cats[2], 0, 128))  # conv_a_2 = the level-2 skip, :105
         self._conv(scope, L["conv2"], (c1[N:], 0, 64), (c2b, 0, 128))

@@ -189,6 +189,11 @@ int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, int pad
 /* image fp32 [n_img,h,w,3] -> batch rows [n0, n0+n_img) of the out view, 3 (pad 8) channels
  * (the siamese towers of FlowNetC run as one 2N batch, flownet_c.py:30-37) */
 int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, int pad, void* stream);
+/* Space-to-depth variant for a stride-2 stem on a 3-channel image: out[n, sy, sx, (py*2+px)*4 + c] =
+ * zero-padded img[2sy+py-pad, 2sx+px-pad, c]; out is the WHOLE [n_total, (h+2pad)/2, (w+2pad)/2, 16] buffer.  The
+ * k x k stride-2 convolution becomes a ceil(k/2)^2 stride-1 kind-2 convolution with the weights re-indexed
+ * w'[ky', kx', (py*2+px)*4+c] = w[2ky'+py, 2kx'+px, c] (zero past k). */
+int fn2_pack_image_s2d(const float* img, int n_img, int h, int w, const fn2_tensor* out, int n0, int pad, void* stream);
 
 /* FlowNetC correlation inside the engine: a, b views over conv3 features (C multiple of 32),
  * out = LeakyReLU(correlation(a, b, 1, md, 1, s2, md)) written into a channel slice
