@@ -1,0 +1,54 @@
+#!/bin/bash
+# Round-end measurement on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r01
+# Writes rocprofv3 kernel statistics, the bench JSON lines and the PMC traffic summaries under gpurun_out/profiles_<tag>/
+# (copy what should be judged into profiles/).  Counters are collected in their own passes (no trace domains mixed in).
+set -e
+tag=${1:-r01}
+root=$(pwd)
+out=$root/gpurun_out/profiles_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+
+stats() {  # name, bench args...
+  local name=$1; shift
+  rm -rf $out/tmp_$name
+  rocprofv3 --kernel-trace --stats -d $out/tmp_$name --output-format csv -- python $root/bench.py "$@" --no-cpu-baseline \
+      > $out/${tag}_${name}_bench_under_rocprof.json 2> $out/tmp_$name.err
+  cp $(ls $out/tmp_$name/*/*kernel_stats.csv | head -1) $out/${tag}_${name}_kernel_stats.csv
+  rm -rf $out/tmp_$name
+  echo "stats $name done"
+}
+
+stats flownetc_b8_f16x2 --steps 30 --warmup 5
+stats flownetc_b8_bf16 --steps 30 --warmup 5 --dtype bf16
+stats flownetc_b8_f32 --steps 30 --warmup 5 --dtype f32
+stats flownet2_b4_f16x2 --model FlowNet2 --batch 4 --steps 20 --warmup 3
+stats flownets_train_b8_f32 --mode train --steps 10 --warmup 3
+
+pmc() {  # name, counter, bench args...
+  local name=$1 counter=$2; shift 2
+  rm -rf $out/pmc_${name}_$counter
+  rocprofv3 --kernel-trace --pmc $counter -d $out/pmc_${name}_$counter --output-format csv -- python $root/bench.py "$@" \
+      --no-cpu-baseline --no-graph --steps 3 --warmup 1 > /dev/null 2> $out/pmc_${name}_$counter.err
+}
+for cfg in "FlowNetC_b8_f16x2 --dtype f16x2" "FlowNetC_b8_f32 --dtype f32"; do
+  set -- $cfg
+  name=$1; shift
+  pmc $name FETCH_SIZE "$@"
+  pmc $name WRITE_SIZE "$@"
+  python $root/tools/pmc_traffic.py $(ls $out/pmc_${name}_FETCH_SIZE/*/*counter_collection.csv | head -1) \
+      $(ls $out/pmc_${name}_WRITE_SIZE/*/*counter_collection.csv | head -1) > $out/pmc_traffic_$name.json
+  rm -rf $out/pmc_${name}_FETCH_SIZE $out/pmc_${name}_WRITE_SIZE
+  echo "pmc $name done"
+done
+
+python $root/tools/bench_ops.py > $out/${tag}_ops_bandwidth_b8.json 2> /dev/null
+python $root/tools/bench_ops.py --batch 64 > $out/${tag}_ops_bandwidth_b64.json 2> /dev/null
+# the plain (un-profiled) headline run, CPU baseline included
+python $root/bench.py --steps 30 --warmup 5 > $out/${tag}_flownetc_b8_f16x2_bench.json 2> /dev/null
+python $root/bench.py --model FlowNet2 --batch 4 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_flownet2_b4_f16x2_bench.json 2> /dev/null
+python $root/bench.py --model FlowNet2 --batch 4 --height 448 --width 1024 --steps 10 --warmup 3 --no-cpu-baseline \
+    > $out/${tag}_flownet2_b4_1024x448_f16x2_bench.json 2> /dev/null
+python $root/bench.py --mode train --steps 10 --warmup 3 > $out/${tag}_flownets_train_b8_f32_bench.json 2> /dev/null
+ls -la $out
