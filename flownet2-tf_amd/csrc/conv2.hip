@@ -144,17 +144,24 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     vmask[j] = mk;
   }
   // wave-uniform state of stage kt0: tap (ky, kx) and 128-byte block `sc` inside the tap's channel run
-  const int spt = p.cin_chunks >> 3;  // stages per tap
-  int tap = kt0 / spt;
-  int sc = kt0 - tap * spt;
+  // K order: 128-byte channel block OUTER, filter tap INNER.  The taps of one channel block re-touch the same
+  // 128-byte lines of neighbouring pixels within KH*KW consecutive stages, so a block's live set is one line per
+  // halo pixel (tens of KB) and stays in its XCD's L2; with the tap outer (the first version) the re-touch
+  // distance was a whole pass over the channels and every tap missed L2: FETCH_SIZE showed the 3x3 layers
+  // fetching their input 6-9 times (conv3_1: 449 MB for a 47 MB input).  Only the summation order changes.
+  const int spt = p.cin_chunks >> 3;  // 128-byte stages per tap
+  const int ntap = p.KH * p.KW;
+  const bool tap_outer = p.dbg & 16;  // A/B switch: the first version's order
+  int sc = tap_outer ? kt0 % spt : kt0 / ntap;  // channel block of stage kt0
+  int tap = tap_outer ? kt0 / spt : kt0 - sc * ntap;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
-  int wstage = kt0;  // absolute stage index of the next weight fetch
+  int wstage = kt0;  // position in this order; the weight row offset of the stage is ((ky*KW + kx)*spt + sc) * 128
 
   auto issue_piece = [&](auto piece_c, uint4* lds) {
     constexpr int i = decltype(piece_c)::value;
     if constexpr (i < NWI) {
       if (!(p.dbg & 2))
-        dma16(rsrc_w, &lds[(wave * (BC / 4) + i * 8) * 8], woff[i], wstage * 128);
+        dma16(rsrc_w, &lds[(wave * (BC / 4) + i * 8) * 8], woff[i], ((ky * p.KW + kx) * spt + sc) * 128);
     } else {
       constexpr int j = i - NWI;
       const unsigned tbit = (1u << ky) | (1u << (8 + kx));
@@ -166,9 +173,15 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   };
   auto advance = [&]() {
     ++wstage;
-    if (++sc == spt) {
-      sc = 0;
-      if (++kx == p.KW) { kx = 0; ++ky; }
+    if (tap_outer) {
+      if (++sc == spt) {
+        sc = 0;
+        if (++kx == p.KW) { kx = 0; ++ky; }
+      }
+      if (ky == p.KH) { ky = 0; sc = spt; }  // past the end: park on an always-masked state
+    } else if (++kx == p.KW) {
+      kx = 0;
+      if (++ky == p.KH) { ky = 0; ++sc; }
     }
   };
   auto issue_stage = [&](uint4* lds) {
