@@ -613,6 +613,14 @@ static bool is_flow_head(const fn2_conv_desc* d) {
 }
 // Cout == 2 layers that are not 3x3/s1/p1 fp32-out heads run on the generic kernel (16-cout tile)
 
+// 128-cout layers of the LDS-DMA kernel whose 128-pixel grid is under 384 blocks take 64-pixel tiles -- when that
+// gives at least 192 blocks (the 24x32 / 12x16 levels: +17-19 %; at 6x8 the split-K count is what matters and the
+// narrower tile only adds weight re-reads: -10 %, measured)
+static bool wants_bp64(const ConvArgs& a, int tile, int phases, int layout) {
+  const long ct = (long)(a.cout_pad / 128) * phases;
+  return layout == 1 && tile == 128 && !(a.dbg & 32) && cdiv(a.M, 128) * ct < 384 && cdiv(a.M, 64) * ct >= 192;
+}
+
 // validate + fill everything except the split-K fields
 static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int* phases_out) {
   FN2_REQUIRE(d, "conv2d: null descriptor");
@@ -720,6 +728,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     FN2_REQUIRE((long)d->cout_pad * d->kpad * esz < (1L << 31), "conv2d: packed weight >= 2 GiB per phase");
     a.in_bytes = (int)in_bytes;
   }
+  a.bp64 = wants_bp64(a, tile, phases, d->wgt_layout) ? 1 : 0;
   *tile_out = tile;
   *phases_out = phases;
   return FN2_OK;
@@ -728,7 +737,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
 // Preferred split-K factor: fill >= ~2 blocks per CU on layers whose output grid is small
 // (the 6x8 .. 24x32 resolution layers: weight-bandwidth bound, SURVEY.md section 7 "hard parts").
 static int preferred_split(const ConvArgs& a, int tile, int phases) {
-  const int bp = tile == 128 ? 128 : 256;  // 64- and 32-cout tiles span 256 pixels
+  const int bp = tile == 128 ? (a.bp64 ? 64 : 128) : 256;  // 64- and 32-cout tiles span 256 pixels
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
   if (blocks >= 384) return 1;
   int s = (int)((512 + blocks - 1) / blocks);

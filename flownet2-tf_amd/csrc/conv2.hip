@@ -61,12 +61,14 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
 
 // TCN = 32-cout MFMA tiles per wave (2: the 128x128 / 64x256 blocks; 1: a 32-cout x 256-pixel block for the
 // Cout <= 32 layers -- full-resolution fusion layers, conv_redir -- whose 64-cout tile was half or more padding).
-template <typename T, typename OutT, int WC, int WP, int TCN = 2>
+// TPN = 32-pixel MFMA tiles per wave (1: a 128-cout x 64-pixel block for mid-size layers whose 128 x 128 grid
+// would not fill the chip: twice the blocks instead of split-K slabs + a finalize launch).
+template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2>
 __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
   constexpr int ESZ = (int)sizeof(T);
-  constexpr int BC = WC * TCN * 32, BP = WP * 64;
+  constexpr int BC = WC * TCN * 32, BP = WP * TPN * 32;
   static_assert(WC * WP == 4, "4 waves per block");
   constexpr int NWI = BC / 32;  // weight-row DMA pieces per wave per stage (8 rows each)
   constexpr int NPI = BP / 32;  // pixel-row DMA pieces per wave per stage
@@ -193,18 +195,18 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 
   // ---- fragment addresses: row r = l&31 of a 32-row tile, chunk 2*ks + (l>>5), swizzled by the row
   const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-  f32x16 acc[TCN][2];
+  f32x16 acc[TCN][TPN];
 #pragma unroll
   for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp)
+    for (int tp = 0; tp < TPN; ++tp)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[tc][tp][q] = 0.f;
 
   // one stage of MFMAs on the LDS object `lds`
   auto compute = [&](const uint4* lds) {
     const uint4* A = &lds[(wc * TCN * 32 + fr) * 8];
-    const uint4* B = &lds[(BC + wp * 64 + fr) * 8];
+    const uint4* B = &lds[(BC + wp * TPN * 32 + fr) * 8];
     if constexpr (is_x2<T>::value) {
       // split fp16: the 128-byte row is [hi g0 | lo g0 | hi g1 | lo g1 | hi g2 | lo g2 | hi g3 | lo g3]
       // (4 groups of 8 channels).  One 32x32x16 product covers groups (2q, 2q+1): lane half h owns
@@ -212,15 +214,15 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
-        uint4 ah[TCN], al[TCN], bh[2], bl[2];
+        uint4 ah[TCN], al[TCN], bh[TPN], bl[TPN];
 #pragma unroll
         for (int t = 0; t < TCN; ++t) { ah[t] = A[t * 32 * 8 + chh]; al[t] = A[t * 32 * 8 + chl]; }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { bh[t] = B[t * 32 * 8 + chh]; bl[t] = B[t * 32 * 8 + chl]; }
+        for (int t = 0; t < TPN; ++t) { bh[t] = B[t * 32 * 8 + chh]; bl[t] = B[t * 32 * 8 + chl]; }
 #pragma unroll
         for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
-          for (int tp = 0; tp < 2; ++tp) {
+          for (int tp = 0; tp < TPN; ++tp) {
             acc[tc][tp] = mfma_32x32x16<f16_t>(al[tc], bh[tp], acc[tc][tp]);
             acc[tc][tp] = mfma_32x32x16<f16_t>(ah[tc], bl[tp], acc[tc][tp]);
             acc[tc][tp] = mfma_32x32x16<f16_t>(ah[tc], bh[tp], acc[tc][tp]);
@@ -228,12 +230,13 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       }
     } else {
       // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
-      uint4 fa[2][TCN], fb[2][2];
+      uint4 fa[2][TCN], fb[2][TPN];
       {
         const int ch = fh ^ fsw;
 #pragma unroll
         for (int t = 0; t < TCN; ++t) fa[0][t] = A[t * 32 * 8 + ch];
-        fb[0][0] = B[ch]; fb[0][1] = B[32 * 8 + ch];
+#pragma unroll
+        for (int t = 0; t < TPN; ++t) fb[0][t] = B[t * 32 * 8 + ch];
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -242,13 +245,14 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
           const int ch = ((ks + 1) * 2 + fh) ^ fsw;
 #pragma unroll
           for (int t = 0; t < TCN; ++t) fa[nxt][t] = A[t * 32 * 8 + ch];
-          fb[nxt][0] = B[ch]; fb[nxt][1] = B[32 * 8 + ch];
+#pragma unroll
+          for (int t = 0; t < TPN; ++t) fb[nxt][t] = B[t * 32 * 8 + ch];
         }
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
           for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp)
+            for (int tp = 0; tp < TPN; ++tp)
               acc[tc][tp] = mfma_32x32x16<T>(fa[cur][tc], fb[cur][tp], acc[tc][tp]);
         } else {
           // chunk = 4 floats; MFMA j takes element j of both operands (a permutation of k shared by both)
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
             for (int tc = 0; tc < TCN; ++tc)
 #pragma unroll
-              for (int tp = 0; tp < 2; ++tp)
+              for (int tp = 0; tp < TPN; ++tp)
                 acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, fa[cur][tc])[j],
                                                                    __builtin_bit_cast(f32x4, fb[cur][tp])[j],
                                                                    acc[tc][tp], 0, 0, 0);
@@ -294,8 +298,8 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   if (p.splitk > 1) {
     float* slab = p.ws + (size_t)split * p.N * p.out_H * p.out_W * p.ws_cs;
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-      const int m = m0 + wp * 64 + tp * 32 + fr;
+    for (int tp = 0; tp < TPN; ++tp) {
+      const int m = m0 + wp * TPN * 32 + tp * 32 + fr;
       if (m >= p.M) continue;
       const int n = m / (p.OH * p.OW);
       const int rem = m - n * (p.OH * p.OW);
@@ -321,8 +325,8 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) bias[q] = (p.bias != nullptr && cout_base + q < p.Cout) ? p.bias[cout_base + q] : 0.f;
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-      const int m = m0 + wp * 64 + tp * 32 + fr;
+    for (int tp = 0; tp < TPN; ++tp) {
+      const int m = m0 + wp * TPN * 32 + tp * 32 + fr;
       if (m >= p.M) continue;
       const int n = m / (p.OH * p.OW);
       const int rem = m - n * (p.OH * p.OW);
@@ -355,7 +359,10 @@ template <typename T, typename OutT>
 static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   dim3 block(256);
   const int z = phases * a.splitk;
-  if (tile == 128) {
+  if (tile == 128 && a.bp64) {
+    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1>), grid, block, 0, s, a);
+  } else if (tile == 128) {
     dim3 grid(cdiv(a.M, 128), a.cout_pad / 128, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2>), grid, block, 0, s, a);
   } else if (tile == 64) {

@@ -29,7 +29,15 @@ from . import _hip, netdefs, weights as W
 # on the fp16 matrix cores; buffers are float32 containers (4 bytes per channel).
 _DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f16x2": torch.float32}
 _CODE = {"f32": _hip.FN2_F32, "bf16": _hip.FN2_BF16, "f16": _hip.FN2_F16, "f16x2": _hip.FN2_F16X2}
-_TILE_ARGS = {128: "2, 2, 2", 64: "1, 4, 2", 32: "1, 4, 1"}  # conv_igemm2_kernel<.., WC, WP, TCN> per cout tile
+_TILE_ARGS = {128: "2, 2, 2, 2", 64: "1, 4, 2, 2", 32: "1, 4, 1, 2"}  # conv_igemm2_kernel<.., WC, WP, TCN, TPN> per cout tile
+
+
+def conv2_kernel_args(tile, m, cout_pad, phases):
+    """Template arguments of the conv_igemm2_kernel instantiation the library picks (conv.hip: wants_bp64)."""
+    ct = (cout_pad // 128) * phases
+    if tile == 128 and -(-m // 128) * ct < 384 and -(-m // 64) * ct >= 192:
+        return "2, 2, 2, 1"
+    return _TILE_ARGS[tile]
 _TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16", "f16x2": "fn2::x2_t"}
 
 
@@ -161,7 +169,8 @@ class Engine:
             kern = f"flow_head_kernel<{tn}>"
         elif layout == 1:
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
-            kern = f"conv_igemm2_kernel<{tn}, {on}, {_TILE_ARGS[tile]}>"
+            m_px = dbuf.shape[0] * dbuf.shape[1] * dbuf.shape[2] // (4 if kind != "conv" else 1)
+            kern = f"conv_igemm2_kernel<{tn}, {on}, {conv2_kernel_args(tile, m_px, cout_pad, 4 if kind != 'conv' else 1)}>"
         else:
             shape = {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4", 16: "1, 1, 4"}[tile]
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"

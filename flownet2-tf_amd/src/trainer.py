@@ -154,8 +154,11 @@ class FlowNetSTrainer:
         self.keep += [d, wb, gmap]
         self.eng.conv_descs.append(d)  # shares the split-K workspace
         if plan.layout == 1:
-            from .engine import _TILE_ARGS
-            d.kernel_name = "conv_igemm2_kernel<float, float, %s>" % _TILE_ARGS[plan.cout_tile]
+            from .engine import conv2_kernel_args
+            gxs = gx_buf.shape
+            m_px = gxs[0] * gxs[1] * gxs[2] // (4 if kind == 3 else 1)
+            d.kernel_name = "conv_igemm2_kernel<float, float, %s>" % conv2_kernel_args(plan.cout_tile, m_px, cout_pad,
+                                                                                       4 if kind == 3 else 1)
         else:
             d.kernel_name = "conv_igemm_kernel<float, float, %s>" % {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4",
                                                                       16: "1, 1, 4"}[plan.cout_tile]
