@@ -613,12 +613,14 @@ static bool is_flow_head(const fn2_conv_desc* d) {
 }
 // Cout == 2 layers that are not 3x3/s1/p1 fp32-out heads run on the generic kernel (16-cout tile)
 
-// 128-cout layers of the LDS-DMA kernel whose 128-pixel grid is under 384 blocks take 64-pixel tiles -- when that
-// gives at least 192 blocks (the 24x32 / 12x16 levels: +17-19 %; at 6x8 the split-K count is what matters and the
-// narrower tile only adds weight re-reads: -10 %, measured)
+// 128-cout layers of the LDS-DMA kernel run on 128 x 64 block tiles (48 KB of LDS: three blocks per CU) whenever
+// that grid has >= 192 blocks.  Measured against the 128 x 128 tile (two blocks per CU): large layers +1..13 %
+// (a third resident block covers more of the DMA / barrier waits than the extra weight fetches cost), the
+// 24x32 / 12x16 levels +17-19 % (no split-K slabs, no finalize launch); at 6x8 the split count is what matters
+// and the narrower tile loses 10 %, so those keep 128 x 128 + split-K.  FN2_CONV_DBG bit 32 = never (A/B).
 static bool wants_bp64(const ConvArgs& a, int tile, int phases, int layout) {
   const long ct = (long)(a.cout_pad / 128) * phases;
-  return layout == 1 && tile == 128 && !(a.dbg & 32) && cdiv(a.M, 128) * ct < 384 && cdiv(a.M, 64) * ct >= 192;
+  return layout == 1 && tile == 128 && !(a.dbg & 32) && cdiv(a.M, 64) * ct >= 192;
 }
 
 // validate + fill everything except the split-K fields

@@ -19,6 +19,7 @@ weights 16-bit, fp32 accumulate, flow heads / warps / resize in fp32).
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -35,7 +36,7 @@ _TILE_ARGS = {128: "2, 2, 2, 2", 64: "1, 4, 2, 2", 32: "1, 4, 1, 2"}  # conv_ige
 def conv2_kernel_args(tile, m, cout_pad, phases):
     """Template arguments of the conv_igemm2_kernel instantiation the library picks (conv.hip: wants_bp64)."""
     ct = (cout_pad // 128) * phases
-    if tile == 128 and -(-m // 128) * ct < 384 and -(-m // 64) * ct >= 192:
+    if tile == 128 and -(-m // 64) * ct >= 192 and not int(os.environ.get("FN2_CONV_DBG", "0")) & 32:
         return "2, 2, 2, 1"
     return _TILE_ARGS[tile]
 _TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16", "f16x2": "fn2::x2_t"}
