@@ -613,14 +613,18 @@ static bool is_flow_head(const fn2_conv_desc* d) {
 }
 // Cout == 2 layers that are not 3x3/s1/p1 fp32-out heads run on the generic kernel (16-cout tile)
 
-// 128-cout layers of the LDS-DMA kernel run on 128 x 64 block tiles (48 KB of LDS: three blocks per CU) whenever
-// that grid has >= 192 blocks.  Measured against the 128 x 128 tile (two blocks per CU): large layers +1..13 %
-// (a third resident block covers more of the DMA / barrier waits than the extra weight fetches cost), the
-// 24x32 / 12x16 levels +17-19 % (no split-K slabs, no finalize launch); at 6x8 the split count is what matters
-// and the narrower tile loses 10 %, so those keep 128 x 128 + split-K.  FN2_CONV_DBG bit 32 = never (A/B).
+// Block tiles of the LDS-DMA kernel are HALF as wide in pixels as the first version's (128 x 64, 64 x 128,
+// 32 x 128 instead of 128 x 128, 64 x 256, 32 x 256): 40-48 KB of LDS = three or four resident blocks per CU instead
+// of two.  Measured (tools/ab_conv.py, tools/ab_e2e.sh on one box): large 128-cout layers +1..13 % (the extra
+// resident block covers more of the DMA / barrier waits than the extra weight fetches cost), 24x32 / 12x16 levels
+// +17-19 % (no split-K slabs, no finalize launch), 64- and 32-cout layers +10..17 %; FlowNetC b8 -3.5 %,
+// FlowNet2 b4 -8 % end to end.  Exception: 128-cout layers whose half-width grid is still under 192 blocks (the 6x8
+// level) -- there the split-K count is what matters and the narrow tile loses 10 %.  FN2_CONV_DBG bit 32 = the
+// full-width tiles (A/B).
 static bool wants_bp64(const ConvArgs& a, int tile, int phases, int layout) {
-  const long ct = (long)(a.cout_pad / 128) * phases;
-  return layout == 1 && tile == 128 && !(a.dbg & 32) && cdiv(a.M, 64) * ct >= 192;
+  if (layout != 1 || (a.dbg & 32)) return false;
+  if (tile < 128) return true;
+  return cdiv(a.M, 64) * (long)(a.cout_pad / 128) * phases >= 192;
 }
 
 // validate + fill everything except the split-K fields
@@ -739,7 +743,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
 // Preferred split-K factor: fill >= ~2 blocks per CU on layers whose output grid is small
 // (the 6x8 .. 24x32 resolution layers: weight-bandwidth bound, SURVEY.md section 7 "hard parts").
 static int preferred_split(const ConvArgs& a, int tile, int phases) {
-  const int bp = tile == 128 ? (a.bp64 ? 64 : 128) : 256;  // 64- and 32-cout tiles span 256 pixels
+  const int bp = tile == 128 ? (a.bp64 ? 64 : 128) : (a.bp64 ? 128 : 256);
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
   if (blocks >= 384) return 1;
   int s = (int)((512 + blocks - 1) / blocks);

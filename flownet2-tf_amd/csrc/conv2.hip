@@ -365,9 +365,15 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   } else if (tile == 128) {
     dim3 grid(cdiv(a.M, 128), a.cout_pad / 128, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2>), grid, block, 0, s, a);
+  } else if (tile == 64 && a.bp64) {
+    dim3 grid(cdiv(a.M, 128), a.cout_pad / 64, z);
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4, 2, 1>), grid, block, 0, s, a);
   } else if (tile == 64) {
     dim3 grid(cdiv(a.M, 256), a.cout_pad / 64, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4>), grid, block, 0, s, a);
+  } else if (a.bp64) {
+    dim3 grid(cdiv(a.M, 128), a.cout_pad / 32, z);
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4, 1, 1>), grid, block, 0, s, a);
   } else {
     dim3 grid(cdiv(a.M, 256), a.cout_pad / 32, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4, 1>), grid, block, 0, s, a);

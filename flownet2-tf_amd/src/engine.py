@@ -35,10 +35,15 @@ _TILE_ARGS = {128: "2, 2, 2, 2", 64: "1, 4, 2, 2", 32: "1, 4, 1, 2"}  # conv_ige
 
 def conv2_kernel_args(tile, m, cout_pad, phases):
     """Template arguments of the conv_igemm2_kernel instantiation the library picks (conv.hip: wants_bp64)."""
-    ct = (cout_pad // 128) * phases
-    if tile == 128 and -(-m // 64) * ct >= 192 and not int(os.environ.get("FN2_CONV_DBG", "0")) & 32:
+    if int(os.environ.get("FN2_CONV_DBG", "0")) & 32:
+        return _TILE_ARGS[tile]
+    if tile < 128:
+        return {64: "1, 4, 2, 1", 32: "1, 4, 1, 1"}[tile]
+    if -(-m // 64) * (cout_pad // 128) * phases >= 192:
         return "2, 2, 2, 1"
     return _TILE_ARGS[tile]
+
+
 _TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16", "f16x2": "fn2::x2_t"}
 
 
@@ -221,7 +226,7 @@ class Engine:
         self.conv_descs.append(d)
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
-                 kernel=f"conv_igemm2_kernel<{tn}, float, {_TILE_ARGS[plan.cout_tile]}>")
+                 kernel=f"conv_igemm2_kernel<{tn}, float, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1)}>")
         self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(self._head_t), 32, _hip.ptr(bias),
                  _hip.ptr(pf), n, h, wd)
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
@@ -278,7 +283,7 @@ class Engine:
                                 kstep=plan.kstep_elems, cs=cs))
         tn = _TNAME[self.dtype_name]
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
-                 kernel=f"conv_igemm2_kernel<{tn}, {tn}, {_TILE_ARGS[plan.cout_tile]}>")
+                 kernel=f"conv_igemm2_kernel<{tn}, {tn}, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1)}>")
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * k_alg * k_alg * cin_alg * cout))
 
