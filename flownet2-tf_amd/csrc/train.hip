@@ -67,20 +67,38 @@ __global__ void __launch_bounds__(256) act_bias_bwd_kernel(const float* __restri
   const long per = (npix + gridDim.y - 1) / gridDim.y;
   const long p0 = (long)blockIdx.y * per, p1 = min(npix, p0 + per);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (ch < c)
-    for (long pix = p0 + tr; pix < p1; pix += rows) {
+  auto slope = [](float yv) { return yv > 0.f ? 1.f : (yv < 0.f ? 0.1f : 0.55f); };
+  if (ch < c) {
+    // four pixels per trip: all eight loads are issued before the first use (one wave keeps 8 x 1 KB in flight;
+    // with one pixel per trip the pass ran at a third of the bandwidth)
+    long pix = p0 + tr;
+    for (; pix + 3L * rows < p1; pix += 4L * rows) {
+      float4 gv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gv[u] = *reinterpret_cast<const float4*>(g + (pix + (long)u * rows) * g_cs + g_c0 + ch);
+        if constexpr (ACT) yv[u] = *reinterpret_cast<const float4*>(y + (pix + (long)u * rows) * y_cs + y_c0 + ch);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (ACT) {
+          gv[u].x *= slope(yv[u].x); gv[u].y *= slope(yv[u].y); gv[u].z *= slope(yv[u].z); gv[u].w *= slope(yv[u].w);
+          *reinterpret_cast<float4*>(g + (pix + (long)u * rows) * g_cs + g_c0 + ch) = gv[u];
+        }
+        acc.x += gv[u].x; acc.y += gv[u].y; acc.z += gv[u].z; acc.w += gv[u].w;
+      }
+    }
+    for (; pix < p1; pix += rows) {
       float4* gp = reinterpret_cast<float4*>(g + pix * g_cs + g_c0 + ch);
       float4 gv = *gp;
       if constexpr (ACT) {
         const float4 yv = *reinterpret_cast<const float4*>(y + pix * y_cs + y_c0 + ch);
-        gv.x *= yv.x > 0.f ? 1.f : (yv.x < 0.f ? 0.1f : 0.55f);
-        gv.y *= yv.y > 0.f ? 1.f : (yv.y < 0.f ? 0.1f : 0.55f);
-        gv.z *= yv.z > 0.f ? 1.f : (yv.z < 0.f ? 0.1f : 0.55f);
-        gv.w *= yv.w > 0.f ? 1.f : (yv.w < 0.f ? 0.1f : 0.55f);
+        gv.x *= slope(yv.x); gv.y *= slope(yv.y); gv.z *= slope(yv.z); gv.w *= slope(yv.w);
         *gp = gv;
       }
       acc.x += gv.x; acc.y += gv.y; acc.z += gv.z; acc.w += gv.w;
     }
+  }
   if (db == nullptr) return;
   __shared__ float4 s[256];
   s[threadIdx.x] = acc;
@@ -325,7 +343,9 @@ __device__ __forceinline__ int perm32(int r) {  // packed row of output channel 
 
 // SWAP: the MFMA computes D^T (lane = i, registers = j) so that the atomics of a wave instruction are
 // contiguous when i is the fastest index of dw (the transposed convolutions, stride_i == 1).
-template <bool SWAP>
+// NI x NJ = 32x32 MFMA tiles per wave (block tile 64*NI x 64*NJ): layers with <= 64 channels on a side (the
+// stems, conv2, deconv2) would waste half or three quarters of a 128-wide tile's matrix work.
+template <bool SWAP, int NI, int NJ>
 __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PK = 32;  // pixels per stage
@@ -336,9 +356,10 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1;
-  const int i0 = blockIdx.x * 128;
-  const int njt = (p.Cj + 127) / 128;
-  const int tap = blockIdx.y / njt, j0 = (blockIdx.y - tap * njt) * 128;
+  constexpr int TI = 64 * NI, TJ = 64 * NJ;
+  const int i0 = blockIdx.x * TI;
+  const int njt = (p.Cj + TJ - 1) / TJ;
+  const int tap = blockIdx.y / njt, j0 = (blockIdx.y - tap * njt) * TJ;
   const int ky = tap / p.KW, kx = tap - ky * p.KW;
   const int pbeg = blockIdx.z * p.pix_per_split, pend = min(p.P, pbeg + p.pix_per_split);
   if (pbeg >= pend) return;
@@ -350,7 +371,7 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
   // DMA pieces: one wave instruction = 2 pixel rows x 512 B.  Per stage 16 pieces per tensor, 4 per wave each.
   // lane -> (row lane>>5 of the piece, 16-byte chunk lane&31 = channels 4*(lane&31)..+3)
   const int lrow = lane >> 5, lch = (lane & 31) * 4;
-  const bool ch_ok_d = i0 + lch < p.Ci, ch_ok_s = j0 + lch < p.Cj;
+  const bool ch_ok_d = lch < TI && i0 + lch < p.Ci, ch_ok_s = lch < TJ && j0 + lch < p.Cj;
   // sampled-tensor pixel state of this lane's 4 rows: r = (wave*4 + k)*2 + lrow within the stage
   int sn[4], sy[4], sx[4];
 #pragma unroll
@@ -377,33 +398,33 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NJ; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
   const int fr = lane & 31, fk = lane >> 5;
   auto compute = [&](const float (*lds)[PK * 128]) {
-    const float* Dn = &lds[0][wi * 64 + fr];
-    const float* Sm = &lds[1][wj * 64 + fr];
+    const float* Dn = &lds[0][wi * NI * 32 + fr];
+    const float* Sm = &lds[1][wj * NJ * 32 + fr];
 #pragma unroll
     for (int kk = 0; kk < PK; kk += 2) {
       const int row = (kk + fk) * 128;
-      const float a0 = Dn[row], a1 = Dn[row + 32], b0 = Sm[row], b1 = Sm[row + 32];
-      if constexpr (SWAP) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
-      } else {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      }
+      float av[NI], bv[NJ];
+#pragma unroll
+      for (int t = 0; t < NI; ++t) av[t] = Dn[row + 32 * t];
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) bv[t] = Sm[row + 32 * t];
+#pragma unroll
+      for (int ti = 0; ti < NI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NJ; ++tj) {
+          if constexpr (SWAP) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[tj], av[ti], acc[ti][tj], 0, 0, 0);
+          else acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+        }
     }
   };
   issue(0, lds0);
@@ -424,25 +445,25 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
   // D layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); (row, col) = (i, j), or (j, i) if SWAP
   float* base = p.dw + p.tap_base[tap];
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int ti = 0; ti < NI; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
+    for (int tj = 0; tj < NJ; ++tj) {
       if constexpr (SWAP) {
-        const int i = i0 + wi * 64 + ti * 32 + fr;
+        const int i = i0 + wi * NI * 32 + ti * 32 + fr;
         if (i >= p.Ci) continue;
         const long oi = (long)(p.perm_i ? perm32(i) : i) * p.stride_i;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int j = j0 + wj * 64 + tj * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+          const int j = j0 + wj * NJ * 32 + tj * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
           if (j < p.Cj) atomicAdd(base + (long)(p.perm_j ? perm32(j) : j) * p.stride_j + oi, acc[ti][tj][q]);
         }
       } else {
-        const int j = j0 + wj * 64 + tj * 32 + fr;
+        const int j = j0 + wj * NJ * 32 + tj * 32 + fr;
         if (j >= p.Cj) continue;
         const long oj = (long)(p.perm_j ? perm32(j) : j) * p.stride_j;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int i = i0 + wi * 64 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+          const int i = i0 + wi * NI * 32 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
           if (i < p.Ci) atomicAdd(base + (long)(p.perm_i ? perm32(i) : i) * p.stride_i + oj, acc[ti][tj][q]);
         }
       }
@@ -481,8 +502,10 @@ int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* str
               "leaky_bwd: channel slice must be 4-aligned");
   const long npix = (long)y->n * y->h * y->w;
   const int l2 = gpb_log2_for(y->c / 4);
-  long splits = (npix + 63) / 64;
-  if (splits > 2048) splits = 2048;
+  // few, fat blocks: every block ends with one atomic per channel on the SAME db[c] addresses, and 2048 blocks
+  // serialised on them cost more than the pass itself (conv1: 0.22 ms for a 300 MB pass)
+  long splits = (npix + 255) / 256;
+  if (splits > 512) splits = 512;
   hipLaunchKernelGGL(act_bias_bwd_kernel<true>, dim3((y->c / 4 + (1 << l2) - 1) >> l2, (int)splits), dim3(256), 0,
                      (hipStream_t)stream, (const float*)y->data, (float*)g->data, db, npix, y->c, y->cs, y->c0, g->cs,
                      g->c0, l2);
@@ -499,8 +522,8 @@ int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream) {
     hipLaunchKernelGGL(bias_grad2_kernel, dim3(grid_for(npix, 1024)), dim3(256), 0, st, (const float*)g->data, db, npix);
   } else if (g->c % 4 == 0 && g->cs % 4 == 0 && g->c0 % 4 == 0) {
     const int l2 = gpb_log2_for(g->c / 4);
-    long splits = (npix + 63) / 64;
-    if (splits > 2048) splits = 2048;
+    long splits = (npix + 255) / 256;
+    if (splits > 512) splits = 512;
     hipLaunchKernelGGL(act_bias_bwd_kernel<false>, dim3((g->c / 4 + (1 << l2) - 1) >> l2, (int)splits), dim3(256), 0, st,
                        (const float*)nullptr, (float*)g->data, db, npix, g->c, 0, 0, g->cs, g->c0, l2);
   } else {
@@ -613,7 +636,8 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   a.dn_bytes = (int)dnb; a.sm_bytes = (int)smb;
   a.P = dn->n * dn->h * dn->w;
   const int taps = a.KH * a.KW;
-  const int it = (a.Ci + 127) / 128, jt = (a.Cj + 127) / 128;
+  const int ni = a.Ci <= 64 ? 1 : 2, nj = a.Cj <= 64 ? 1 : 2;
+  const int it = (a.Ci + 64 * ni - 1) / (64 * ni), jt = (a.Cj + 64 * nj - 1) / (64 * nj);
   // pixel splits: aim at >= ~1024 blocks, ranges multiples of 32 pixels
   long blocks = (long)it * jt * taps;
   int splits = (int)((1024 + blocks - 1) / blocks);
@@ -622,10 +646,17 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   if (splits < 1) splits = 1;
   a.pix_per_split = (((a.P + splits - 1) / splits) + 31) / 32 * 32;
   splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
-  if (d->kind == 1)
-    hipLaunchKernelGGL(bwd_filter_kernel<true>, dim3(it, jt * taps, splits), dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(bwd_filter_kernel<false>, dim3(it, jt * taps, splits), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(it, jt * taps, splits), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define FN2_BWF(SW_, NI_, NJ_) hipLaunchKernelGGL((bwd_filter_kernel<SW_, NI_, NJ_>), grid, block, 0, st, a)
+  if (d->kind == 1) {
+    if (ni == 2 && nj == 2) FN2_BWF(true, 2, 2); else if (ni == 2) FN2_BWF(true, 2, 1);
+    else if (nj == 2) FN2_BWF(true, 1, 2); else FN2_BWF(true, 1, 1);
+  } else {
+    if (ni == 2 && nj == 2) FN2_BWF(false, 2, 2); else if (ni == 2) FN2_BWF(false, 2, 1);
+    else if (nj == 2) FN2_BWF(false, 1, 2); else FN2_BWF(false, 1, 1);
+  }
+#undef FN2_BWF
   FN2_CHECK_LAUNCH("bwd_filter");
   return FN2_OK;
 }
