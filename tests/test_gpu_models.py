@@ -234,3 +234,23 @@ def test_interp_cli_path_writes_flow(tmp_path, golden_dir):
     assert np.array_equal(flowlib.read_flow(str(tmp_path / "samples" / "0img0_flow.flo")), flow)
     with pytest.raises(ValueError):
         net.test(None, os.path.join(s, "0img0.ppm"), input_type="image_matches", out_path=str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_sintel_shape_through_adapt_x():
+    """BASELINE config 5 shape: a 436 x 1024 pair is zero-padded to 448 x 1024 (net.py:373-388), run, cropped."""
+    from src.flownet_c.flownet_c import FlowNetC
+    from src.net import Mode
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (436, 1024, 3)).astype(np.uint8)
+    b = np.roll(a, (2, -4), (0, 1))
+    net = FlowNetC(mode=Mode.TEST, dtype="f16x2")
+    wts = net.load_weights(None, seed=5)
+    a1, b1, info = net.adapt_x(a, b)
+    assert a1.shape == (1, 448, 1024, 3) and info == (1, 436, 1024, 3)
+    got = net.model({"input_a": a1, "input_b": b1})["flow"][0].float().cpu().numpy()
+    got = net.postproc_y_hat_test(got, (info[-3], info[-2], 2))
+    want = refm.flownet_c(wts, {"input_a": a1, "input_b": b1})["flow"][0, :436]
+    assert got.shape == (436, 1024, 2)
+    d = got.astype(np.float64) - want
+    assert float(np.sqrt((d * d).sum(-1)).mean()) < 1e-3
