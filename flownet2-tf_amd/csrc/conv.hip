@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = acc[t][pt][r] * p.out_scale + bias[t][r];
-        if constexpr (sizeof(OutT) == 4 && !is_x2<OutT>::value) {
-          if (p.accum && co + r < p.Cout) x += reinterpret_cast<const float*>(po)[co + r];
+        if constexpr (sizeof(OutT) == 4) {
+          if (p.accum && co + r < p.Cout) x += load_elem<OutT>(po + co + r);
         }
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
         v[r] = x;
@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
     for (int j = 0; j < 4; ++j) {
       r[j] *= out_scale;
       if (bias != nullptr && co + j < Cout) r[j] += bias[co + j];
-      if constexpr (sizeof(OutT) == 4 && !is_x2<OutT>::value) {
-        if (accum && co + j < Cout) r[j] += reinterpret_cast<const float*>(po)[j];
+      if constexpr (sizeof(OutT) == 4) {
+        if (accum && co + j < Cout) r[j] += load_elem<OutT>(po + j);
       }
       if (act == FN2_ACT_LEAKY) r[j] = leaky(r[j]);
     }
@@ -713,7 +713,8 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     phases = 4;
   }
   a.accum = d->accumulate ? 1 : 0;
-  if (a.accum) FN2_REQUIRE(d->out.dtype == FN2_F32, "conv2d: accumulate needs an fp32 output");
+  if (a.accum) FN2_REQUIRE(d->out.dtype == FN2_F32 || d->out.dtype == FN2_F16X2,
+                           "conv2d: accumulate needs an fp32 or split-fp16 output");
   const long M = (long)a.N * a.OH * a.OW;
   FN2_REQUIRE(M < (1L << 31), "conv2d: too many output pixels");
   a.M = (int)M;

@@ -337,8 +337,8 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float x = acc[tc][tp][q] * p.out_scale + bias[q];
-        if constexpr (sizeof(OutT) == 4 && !is_x2<OutT>::value) {
-          if (p.accum && cout_base + q < p.Cout) x += reinterpret_cast<const float*>(po)[q];
+        if constexpr (sizeof(OutT) == 4) {  // fp32 and split-fp16 outputs can accumulate (gradient buffers)
+          if (p.accum && cout_base + q < p.Cout) x += load_elem<OutT>(po + q);
         }
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
         v[q] = x;

@@ -88,6 +88,34 @@ __device__ __forceinline__ void store_elem<x2_t>(x2_t* p, float v) {
   g[8 + j] = (_Float16)(v - (float)h);
 }
 
+// scalar load of one element as fp32 (x2: hi + lo of its group; element-addressed pointer)
+template <typename T>
+__device__ __forceinline__ float load_elem(const T* p) { return (float)*p; }
+template <>
+__device__ __forceinline__ float load_elem<x2_t>(const x2_t* p) {
+  const size_t addr = reinterpret_cast<size_t>(p);
+  const _Float16* g = reinterpret_cast<const _Float16*>(addr & ~size_t(31));
+  const int j = (int)((addr & 31) >> 2);
+  return (float)g[j] + (float)g[8 + j];
+}
+
+// 4 consecutive channels starting at a multiple of 4, as fp32
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float* v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (float)p[j];
+}
+template <>
+__device__ __forceinline__ void load4<x2_t>(const x2_t* p, float* v) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  const size_t addr = reinterpret_cast<size_t>(p);
+  const _Float16* g = reinterpret_cast<const _Float16*>(addr & ~size_t(31));
+  const int j0 = (int)((addr & 31) >> 2);
+  const h4 h = *reinterpret_cast<const h4*>(g + j0), l = *reinterpret_cast<const h4*>(g + 8 + j0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (float)h[j] + (float)l[j];
+}
+
 // N consecutive elements converted from fp32 and written with one (N*sizeof(T))-byte store
 template <typename T, int N>
 __device__ __forceinline__ void store_vec(T* p, const float* v) {

@@ -32,7 +32,8 @@ __device__ __forceinline__ float wave_sum_t(float v) {
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) epe_loss_grad_kernel(const float* __restrict__ pred,
                                                             const float* __restrict__ label, float* __restrict__ dpred,
-                                                            float* __restrict__ loss_accum, long npix, float scale) {
+                                                            float* __restrict__ loss_accum, long npix, float scale,
+                                                            float grad_mult) {
   float part = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
     const float2 p = *reinterpret_cast<const float2*>(pred + 2 * i);
@@ -40,7 +41,7 @@ __global__ void __launch_bounds__(256) epe_loss_grad_kernel(const float* __restr
     const float du = p.x - l.x, dv = p.y - l.y;
     const float e = sqrtf(du * du + dv * dv);
     part += e;
-    const float inv = e > 0.f ? scale / e : 0.f;
+    const float inv = e > 0.f ? scale * grad_mult / e : 0.f;
     *reinterpret_cast<float2*>(dpred + 2 * i) = make_float2(du * inv, dv * inv);
   }
   part = wave_sum_t(part);
@@ -112,6 +113,64 @@ __global__ void __launch_bounds__(256) act_bias_bwd_kernel(const float* __restri
   }
 }
 
+// Split-fp16 form of the same pass (gradient and activation buffers of the f16x2 trainer): a thread owns one group
+// of 8 channels of a pixel (16 B of hi parts + 16 B of lo parts per tensor).
+template <bool ACT>
+__global__ void __launch_bounds__(256) act_bias_bwd_x2_kernel(const x2_t* __restrict__ y, x2_t* __restrict__ g,
+                                                              float* __restrict__ db, long npix, int c, int y_cs,
+                                                              int y_c0, int g_cs, int g_c0, int gpb_log2) {
+  const int gpb = 1 << gpb_log2, rows = 256 >> gpb_log2;
+  const int tc = threadIdx.x & (gpb - 1), tr = threadIdx.x >> gpb_log2;
+  const int ch = (blockIdx.x * gpb + tc) * 8;
+  const long per = (npix + gridDim.y - 1) / gridDim.y;
+  const long p0 = (long)blockIdx.y * per, p1 = min(npix, p0 + per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (ch < c)
+    for (long pix = p0 + tr; pix < p1; pix += rows) {
+      uint4* gp = reinterpret_cast<uint4*>(g + pix * g_cs + g_c0 + ch);
+      float gv[8];
+      join8(gp[0], gp[1], gv);
+      if constexpr (ACT) {
+        const uint4* yp = reinterpret_cast<const uint4*>(y + pix * y_cs + y_c0 + ch);
+        float yv[8];
+        join8(yp[0], yp[1], yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] *= yv[j] > 0.f ? 1.f : (yv[j] < 0.f ? 0.1f : 0.55f);
+        split8(gv, gp[0], gp[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += gv[j];
+    }
+  if (db == nullptr) return;
+  __shared__ float s[256][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[threadIdx.x][j] = acc[j];
+  __syncthreads();
+  if (tr == 0 && ch < c) {
+    for (int r = 1; r < rows; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += s[r * gpb + tc][j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(db + ch + j, acc[j]);
+  }
+}
+
+// fp32 -> split fp16 with a power-of-two scale (the forward / backward weight copies of the f16x2 trainer are
+// derived from the fp32 master every step); map != nullptr: gathered, dst[i] = map[i] >= 0 ? src[map[i]] : 0.
+__global__ void __launch_bounds__(256) to_x2_kernel(const float* __restrict__ src, const int* __restrict__ map,
+                                                    x2_t* __restrict__ dst, long ngroups, float scale) {
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long)gridDim.x * blockDim.x) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (map != nullptr) { const int m = map[gi * 8 + j]; v[j] = m >= 0 ? src[m] * scale : 0.f; }
+      else v[j] = src[gi * 8 + j] * scale;
+    }
+    uint4* q = reinterpret_cast<uint4*>(dst + gi * 8);
+    split8(v, q[0], q[1]);
+  }
+}
+
 // bias gradient of a dense 2-channel tensor (the flow heads): db[0..1] += sum of g over pixels.
 __global__ void __launch_bounds__(256) bias_grad2_kernel(const float* __restrict__ g, float* __restrict__ db, long npix) {
   float a0 = 0.f, a1 = 0.f;
@@ -167,7 +226,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, float*
 
 // upsample_flowXtoY backward (forward: conv-transpose 2->2, k4 s2 crop 1, upsample_flow_kernel in conv.hip):
 //   dpf[n,y,x,i] (+)= sum_{ky,kx,o} g[n,2y+ky-1,2x+kx-1,o] * w[ky,kx,o,i];  dw[ky,kx,o,i] += sum g * pf
-__global__ void __launch_bounds__(256) upsample_flow_bwd_kernel(const float* __restrict__ g, int g_cs, int g_c0,
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_flow_bwd_kernel(const T* __restrict__ g, int g_cs, int g_c0,
                                                                 const float* __restrict__ pf, const float* __restrict__ w,
                                                                 float* __restrict__ dpf, float* __restrict__ dw, int N,
                                                                 int H, int W, int accum) {
@@ -191,8 +251,8 @@ __global__ void __launch_bounds__(256) upsample_flow_bwd_kernel(const float* __r
       for (int kx = 0; kx < 4; ++kx) {
         const int gx = 2 * x + kx - 1;
         if (gx < 0 || gx >= 2 * W) continue;
-        const float* gp = g + (((size_t)n * 2 * H + gy) * 2 * W + gx) * g_cs + g_c0;
-        const float g0 = gp[0], g1 = gp[1];
+        const T* gp = g + (((size_t)n * 2 * H + gy) * 2 * W + gx) * g_cs + g_c0;
+        const float g0 = load_elem<T>(gp), g1 = load_elem<T>(gp + 1);
         const float* ww = sw + (ky * 4 + kx) * 4;  // [o][i]
         r0 += g0 * ww[0] + g1 * ww[2];
         r1 += g0 * ww[1] + g1 * ww[3];
@@ -218,7 +278,8 @@ __global__ void __launch_bounds__(256) upsample_flow_bwd_kernel(const float* __r
 // x is read ONCE: a thread owns 4 channels (one float4 per pixel) and all 9 taps x 2 outputs = 72 accumulators;
 // the 18 g values of a pixel are wave-uniform per 16-lane group (L1 broadcast).  Block = 64 channels x a pixel
 // range; lane = (16 channel groups) x (4 pixel lanes), 4 waves stride the pixels further.  HBM-bound on x.
-__global__ void __launch_bounds__(256) head_bwd_filter_kernel(const float* __restrict__ x, int x_cs, int x_c0, int cin,
+template <typename T>
+__global__ void __launch_bounds__(256) head_bwd_filter_kernel(const T* __restrict__ x, int x_cs, int x_c0, int cin,
                                                               const float* __restrict__ g, float* __restrict__ dw,
                                                               int cin_pad, int kpad, int N, int H, int W) {
   const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;  // 16 pixel lanes per block
@@ -236,8 +297,8 @@ __global__ void __launch_bounds__(256) head_bwd_filter_kernel(const float* __res
   if (ci < cin)
     for (long pix = p0 + pl; pix < p1; pix += 16) {
       const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
-      const float4 xv = *reinterpret_cast<const float4*>(x + pix * x_cs + x_c0 + ci);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      float xs[4];
+      load4<T>(x + pix * x_cs + x_c0 + ci, xs);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int oy = iy - ky + 1;
@@ -280,8 +341,9 @@ __global__ void __launch_bounds__(256) head_bwd_filter_kernel(const float* __res
 // Flow-head input gradient: dx[pix][ci] += sum_{tap,co<2} g[pix - (tap - 1)][co] * w[co][tap*cin_pad + ci]
 // (3x3, stride 1, pad 1; the transpose of the head).  One thread per (pixel, 4 channels); reads the head's own
 // packed weight, so no transposed copy exists.  HBM-bound on the read-modify-write of dx.
+template <typename T>
 __global__ void __launch_bounds__(256) head_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w,
-                                                            float* __restrict__ dx, int dx_cs, int dx_c0, int cin,
+                                                            T* __restrict__ dx, int dx_cs, int dx_c0, int cin,
                                                             int cin_pad, int kpad, int N, int H, int W) {
   const int c4 = (cin + 3) >> 2;
   const long total = (long)N * H * W * c4;
@@ -305,10 +367,18 @@ __global__ void __launch_bounds__(256) head_bwd_data_kernel(const float* __restr
         for (int q = 0; q < 4; ++q) acc[q] += gv.x * w0[q] + gv.y * w1[q];
       }
     }
-    float* d = dx + pix * dx_cs + dx_c0 + ci;
+    T* d = dx + pix * dx_cs + dx_c0 + ci;
+    if constexpr (is_x2<T>::value) {  // whole 4-channel half-groups (the pad channels of the view stay 0 + 0)
+      float cur[4];
+      load4<T>(d, cur);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (ci + q < cin) d[q] += acc[q];
+      for (int q = 0; q < 4; ++q) cur[q] += (ci + q < cin) ? acc[q] : 0.f;
+      store_vec<T, 4>(d, cur);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ci + q < cin) d[q] += acc[q];
+    }
   }
 }
 
@@ -345,7 +415,10 @@ __device__ __forceinline__ int perm32(int r) {  // packed row of output channel 
 // contiguous when i is the fastest index of dw (the transposed convolutions, stride_i == 1).
 // NI x NJ = 32x32 MFMA tiles per wave (block tile 64*NI x 64*NJ): layers with <= 64 channels on a side (the
 // stems, conv2, deconv2) would waste half or three quarters of a 128-wide tile's matrix work.
-template <bool SWAP, int NI, int NJ>
+// X2: both operands are split-fp16 tensors; the DMA moves their rows verbatim (a 16-byte chunk is the hi or the lo
+// half of an 8-channel group) and an operand is rebuilt as hi + lo from two ds_read_u16 when it is fed to the fp32
+// MFMA -- the matrix rate, not LDS, bounds this kernel.
+template <bool SWAP, int NI, int NJ, bool X2 = false>
 __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PK = 32;  // pixels per stage
@@ -371,7 +444,9 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
   // DMA pieces: one wave instruction = 2 pixel rows x 512 B.  Per stage 16 pieces per tensor, 4 per wave each.
   // lane -> (row lane>>5 of the piece, 16-byte chunk lane&31 = channels 4*(lane&31)..+3)
   const int lrow = lane >> 5, lch = (lane & 31) * 4;
-  const bool ch_ok_d = lch < TI && i0 + lch < p.Ci, ch_ok_s = lch < TJ && j0 + lch < p.Cj;
+  // split fp16: chunk lane&31 belongs to the group of channels (lch & ~7)..+7
+  const int lgrp = X2 ? (lch & ~7) : lch;
+  const bool ch_ok_d = lch < TI && i0 + lgrp < p.Ci, ch_ok_s = lch < TJ && j0 + lgrp < p.Cj;
   // sampled-tensor pixel state of this lane's 4 rows: r = (wave*4 + k)*2 + lrow within the stage
   int sn[4], sy[4], sx[4];
 #pragma unroll
@@ -410,14 +485,25 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
   auto compute = [&](const float (*lds)[PK * 128]) {
     const float* Dn = &lds[0][wi * NI * 32 + fr];
     const float* Sm = &lds[1][wj * NJ * 32 + fr];
+    // split fp16: channel ch of a row sits at half-word (ch >> 3) * 16 + (ch & 7) (hi) and + 8 (lo)
+    const int chd = wi * NI * 32 + fr, chs = wj * NJ * 32 + fr;
+    const _Float16* Dh = reinterpret_cast<const _Float16*>(&lds[0][0]) + (chd >> 3) * 16 + (chd & 7);
+    const _Float16* Sh = reinterpret_cast<const _Float16*>(&lds[1][0]) + (chs >> 3) * 16 + (chs & 7);
 #pragma unroll
     for (int kk = 0; kk < PK; kk += 2) {
       const int row = (kk + fk) * 128;
       float av[NI], bv[NJ];
+      if constexpr (X2) {
 #pragma unroll
-      for (int t = 0; t < NI; ++t) av[t] = Dn[row + 32 * t];
+        for (int t = 0; t < NI; ++t) av[t] = (float)Dh[row * 2 + t * 64] + (float)Dh[row * 2 + t * 64 + 8];
 #pragma unroll
-      for (int t = 0; t < NJ; ++t) bv[t] = Sm[row + 32 * t];
+        for (int t = 0; t < NJ; ++t) bv[t] = (float)Sh[row * 2 + t * 64] + (float)Sh[row * 2 + t * 64 + 8];
+      } else {
+#pragma unroll
+        for (int t = 0; t < NI; ++t) av[t] = Dn[row + 32 * t];
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) bv[t] = Sm[row + 32 * t];
+      }
 #pragma unroll
       for (int ti = 0; ti < NI; ++ti)
 #pragma unroll
@@ -471,6 +557,168 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Filter gradient of the split-fp16 trainer on the FP16 matrix cores.  Same tiling, DMA and epilogue as
+// bwd_filter_kernel, but the reduction index of v_mfma_f32_32x32x16_f16 is 16 PIXELS, so an operand is "8
+// consecutive pixels of one channel": a column of the [pixel][channel] LDS tile.  ds_read_b64_tr_b16 delivers
+// exactly that (a 4-pixel x 16-channel block, column-major to the lanes), two per operand half; hi and lo parts
+// are separate 16-byte chunks of a group and give the three products hi*hi + hi*lo + lo*hi.  The 512-byte pixel
+// rows would put the 4 rows of a transposed block on the same banks; the DMA therefore stores logical chunk L of
+// row r at chunk L ^ ((r & 1) | ((r & 2) << 2)) -- the 16 (row, chunk) pairs of a 32-lane read then cover 16
+// distinct chunk positions mod 16.  5x the matrix rate of the fp32 form (96 vs 512 cycles per 16 pixels of a
+// 32 x 32 tile).
+// ---------------------------------------------------------------------------
+template <bool SWAP, int NI, int NJ>
+__global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int PK = 32;
+  __shared__ float lds0[2][PK * 128];
+  __shared__ float lds1[2][PK * 128];
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s4* lds_s4_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;
+  constexpr int TI = 64 * NI, TJ = 64 * NJ;
+  const int i0 = blockIdx.x * TI;
+  const int njt = (p.Cj + TJ - 1) / TJ;
+  const int tap = blockIdx.y / njt, j0 = (blockIdx.y - tap * njt) * TJ;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int pbeg = blockIdx.z * p.pix_per_split, pend = min(p.P, pbeg + p.pix_per_split);
+  if (pbeg >= pend) return;
+  const int nstage = (pend - pbeg + PK - 1) / PK;
+
+  const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dn), 0, p.dn_bytes, 0x00020000);
+  const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.sm), 0, p.sm_bytes, 0x00020000);
+
+  // DMA: lane -> (row lane>>5 of the 2-row piece, physical chunk lane&31); the logical chunk depends on the row
+  const int lrow = lane >> 5, lphys = lane & 31;
+  int sn[4], sy[4], sx[4];
+  unsigned coff_d[4], coff_s[4];  // byte offset of this lane's logical chunk inside the tile's 512-byte row, or OOB
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = (wave * 4 + k) * 2 + lrow;
+    const int pix = pbeg + r;
+    const int n = pix / (p.DH * p.DW_), rem = pix - n * (p.DH * p.DW_);
+    sn[k] = n; sy[k] = rem / p.DW_; sx[k] = rem - sy[k] * p.DW_;
+    const int L = lphys ^ ((r & 1) | ((r & 2) << 2));
+    const int grp_ch = (L >> 1) * 8;  // first channel of the group this chunk belongs to
+    coff_d[k] = (grp_ch < TI && i0 + grp_ch < p.Ci) ? (unsigned)(L * 16) : kOobT;
+    coff_s[k] = (grp_ch < TJ && j0 + grp_ch < p.Cj) ? (unsigned)(L * 16) : kOobT;
+  }
+  auto issue = [&](int st, float (*lds)[PK * 128]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = (wave * 4 + k) * 2;
+      const int pix = pbeg + st * PK + r + lrow;
+      const bool pv = pix < pend;
+      const unsigned vd = (pv && coff_d[k] != kOobT) ? (unsigned)((pix * p.dn_cs + p.dn_c0 + i0) * 4) + coff_d[k] : kOobT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, vd, 0, 0, 0);
+      const int iy = sy[k] * p.stride + ky - p.pad, ix = sx[k] * p.stride + kx - p.pad;
+      const bool sv = pv && coff_s[k] != kOobT && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
+      const unsigned vs = sv ? (unsigned)((((sn[k] * p.SH + iy) * p.SW + ix) * p.sm_cs + p.sm_c0 + j0) * 4) + coff_s[k] : kOobT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[1][r * 128], 16, vs, 0, 0, 0);
+      sx[k] += PK;
+      while (sx[k] >= p.DW_) { sx[k] -= p.DW_; if (++sy[k] == p.DH) { sy[k] = 0; ++sn[k]; } }
+    }
+  };
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < NJ; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  // transposed-read geometry of this lane: 16-lane group gq = channels 16 gq .. +15 of a 32-channel tile, lane
+  // 4q + pq of the group addresses pixel row q, channels 4 pq .. +3; the lane half (lane >> 5) = pixels + 8
+  const int kg = lane >> 5, gq = (lane >> 4) & 1, tq = (lane & 15) >> 2, pq = lane & 3;
+  const int ch_in_tile = 16 * gq + 4 * pq;  // multiple of 4
+  auto frag = [&](const float* tile, int ch0, int part, int pb) -> uint4 {
+    // 8 pixels pb + 8 kg .. +7 of channels ch0 .. (column-major to the lanes): hi (part 0) or lo (part 1) halves
+    const int ch = ch0 + ch_in_tile;
+    const int L = 2 * (ch >> 3) + part;
+    const char* base = reinterpret_cast<const char*>(tile);
+    s4 v[2];
+#pragma unroll
+    for (int sblk = 0; sblk < 2; ++sblk) {
+      const int row = pb + 8 * kg + 4 * sblk + tq;
+      const int phys = L ^ ((row & 1) | ((row & 2) << 2));
+      v[sblk] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(base + row * 512 + phys * 16 + (ch & 4) * 2));
+    }
+    uint4 o;
+    o.x = __builtin_bit_cast(uint2, v[0]).x; o.y = __builtin_bit_cast(uint2, v[0]).y;
+    o.z = __builtin_bit_cast(uint2, v[1]).x; o.w = __builtin_bit_cast(uint2, v[1]).y;
+    return o;
+  };
+  auto compute = [&](const float (*lds)[PK * 128]) {
+#pragma unroll
+    for (int pb = 0; pb < PK; pb += 16) {
+      uint4 ah[NI], al[NI], bh[NJ], bl[NJ];
+#pragma unroll
+      for (int t = 0; t < NI; ++t) { ah[t] = frag(lds[0], wi * NI * 32 + t * 32, 0, pb); al[t] = frag(lds[0], wi * NI * 32 + t * 32, 1, pb); }
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) { bh[t] = frag(lds[1], wj * NJ * 32 + t * 32, 0, pb); bl[t] = frag(lds[1], wj * NJ * 32 + t * 32, 1, pb); }
+#pragma unroll
+      for (int ti = 0; ti < NI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NJ; ++tj) {
+          if constexpr (SWAP) {
+            acc[ti][tj] = mfma_32x32x16<f16_t>(bl[tj], ah[ti], acc[ti][tj]);
+            acc[ti][tj] = mfma_32x32x16<f16_t>(bh[tj], al[ti], acc[ti][tj]);
+            acc[ti][tj] = mfma_32x32x16<f16_t>(bh[tj], ah[ti], acc[ti][tj]);
+          } else {
+            acc[ti][tj] = mfma_32x32x16<f16_t>(al[ti], bh[tj], acc[ti][tj]);
+            acc[ti][tj] = mfma_32x32x16<f16_t>(ah[ti], bl[tj], acc[ti][tj]);
+            acc[ti][tj] = mfma_32x32x16<f16_t>(ah[ti], bh[tj], acc[ti][tj]);
+          }
+        }
+    }
+  };
+  issue(0, lds0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int nstage2 = (nstage + 1) & ~1;
+  for (int st = 0; st < nstage2; st += 2) {
+    issue(st + 1, lds1);
+    compute(lds0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 2 < nstage2) issue(st + 2, lds0);
+    compute(lds1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const int fr = lane & 31, fk = lane >> 5;
+  float* base = p.dw + p.tap_base[tap];
+#pragma unroll
+  for (int ti = 0; ti < NI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < NJ; ++tj) {
+      if constexpr (SWAP) {
+        const int i = i0 + wi * NI * 32 + ti * 32 + fr;
+        if (i >= p.Ci) continue;
+        const long oi = (long)(p.perm_i ? perm32(i) : i) * p.stride_i;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int j = j0 + wj * NJ * 32 + tj * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+          if (j < p.Cj) atomicAdd(base + (long)(p.perm_j ? perm32(j) : j) * p.stride_j + oi, acc[ti][tj][q]);
+        }
+      } else {
+        const int j = j0 + wj * NJ * 32 + tj * 32 + fr;
+        if (j >= p.Cj) continue;
+        const long oj = (long)(p.perm_j ? perm32(j) : j) * p.stride_j;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = i0 + wi * NI * 32 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+          if (i < p.Ci) atomicAdd(base + (long)(p.perm_i ? perm32(i) : i) * p.stride_i + oj, acc[ti][tj][q]);
+        }
+      }
+    }
+#endif
+}
+
 }  // namespace fn2
 
 using namespace fn2;
@@ -478,12 +726,12 @@ using namespace fn2;
 extern "C" {
 
 int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float* loss_accum, int n, int h, int w,
-                      float weight, void* stream) {
+                      float weight, float grad_mult, void* stream) {
   FN2_REQUIRE(pred && label && dpred && loss_accum, "epe_loss_grad: null pointer");
   FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1, "epe_loss_grad: bad dims");
   const long npix = (long)n * h * w;
   hipLaunchKernelGGL(epe_loss_grad_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, pred, label,
-                     dpred, loss_accum, npix, weight / (float)n);
+                     dpred, loss_accum, npix, weight / (float)n, grad_mult);
   FN2_CHECK_LAUNCH("epe_loss_grad");
   return FN2_OK;
 }
@@ -496,8 +744,21 @@ static int gpb_log2_for(int c4) {
 
 int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* stream) {
   FN2_REQUIRE(y && g && y->data && g->data, "leaky_bwd: null tensor");
-  FN2_REQUIRE(y->dtype == FN2_F32 && g->dtype == FN2_F32, "leaky_bwd: fp32 only");
+  FN2_REQUIRE((y->dtype == FN2_F32 || y->dtype == FN2_F16X2) && g->dtype == y->dtype, "leaky_bwd: fp32 or split fp16, both alike");
   FN2_REQUIRE(y->n == g->n && y->h == g->h && y->w == g->w && y->c == g->c, "leaky_bwd: shape mismatch");
+  if (y->dtype == FN2_F16X2) {
+    FN2_REQUIRE(y->c % 8 == 0 && y->cs % 8 == 0 && y->c0 % 8 == 0 && g->cs % 8 == 0 && g->c0 % 8 == 0,
+                "leaky_bwd: split-fp16 slices are group (8) aligned");
+    const long npx = (long)y->n * y->h * y->w;
+    const int l2x = gpb_log2_for(y->c / 8);
+    long sp = (npx + 255) / 256;
+    if (sp > 512) sp = 512;
+    hipLaunchKernelGGL(act_bias_bwd_x2_kernel<true>, dim3((y->c / 8 + (1 << l2x) - 1) >> l2x, (int)sp), dim3(256), 0,
+                       (hipStream_t)stream, (const x2_t*)y->data, (x2_t*)g->data, db, npx, y->c, y->cs, y->c0, g->cs,
+                       g->c0, l2x);
+    FN2_CHECK_LAUNCH("leaky_bwd");
+    return FN2_OK;
+  }
   FN2_REQUIRE(y->c % 4 == 0 && y->cs % 4 == 0 && y->c0 % 4 == 0 && g->cs % 4 == 0 && g->c0 % 4 == 0,
               "leaky_bwd: channel slice must be 4-aligned");
   const long npix = (long)y->n * y->h * y->w;
@@ -536,6 +797,15 @@ int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream) {
   return FN2_OK;
 }
 
+int fn2_to_f16x2(void* dst, const float* src, const int32_t* map, int64_t n, float scale, void* stream) {
+  FN2_REQUIRE(dst && src && n >= 0 && n % 8 == 0, "to_f16x2: n must be a multiple of 8 (whole groups)");
+  if (n == 0) return FN2_OK;
+  hipLaunchKernelGGL(to_x2_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, map, (x2_t*)dst,
+                     (long)(n / 8), scale);
+  FN2_CHECK_LAUNCH("to_f16x2");
+  return FN2_OK;
+}
+
 int fn2_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, void* stream) {
   FN2_REQUIRE(dst && src && map && n >= 0, "gather: bad arguments");
   if (n == 0) return FN2_OK;
@@ -558,40 +828,58 @@ int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float
 int fn2_upsample_flow_bwd(const fn2_tensor* g, const float* pf, const float* w, float* dpf, float* dw, int accumulate,
                           void* stream) {
   FN2_REQUIRE(g && g->data && pf && w && dpf && dw, "upsample_flow_bwd: null pointer");
-  FN2_REQUIRE(g->dtype == FN2_F32 && g->c == 2 && g->h % 2 == 0 && g->w % 2 == 0, "upsample_flow_bwd: g must be a 2-channel fp32 view of even size");
+  FN2_REQUIRE((g->dtype == FN2_F32 || g->dtype == FN2_F16X2) && g->c == 2 && g->h % 2 == 0 && g->w % 2 == 0,
+              "upsample_flow_bwd: g must be a 2-channel fp32 / split-fp16 view of even size");
   const int H = g->h / 2, W = g->w / 2;
-  hipLaunchKernelGGL(upsample_flow_bwd_kernel, dim3(grid_for((long)g->n * H * W, 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const float*)g->data, g->cs, g->c0, pf, w, dpf, dw, g->n, H, W, accumulate);
+  if (g->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(upsample_flow_bwd_kernel<x2_t>, dim3(grid_for((long)g->n * H * W, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const x2_t*)g->data, g->cs, g->c0, pf, w, dpf, dw, g->n, H, W, accumulate);
+  else
+    hipLaunchKernelGGL(upsample_flow_bwd_kernel<float>, dim3(grid_for((long)g->n * H * W, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)g->data, g->cs, g->c0, pf, w, dpf, dw, g->n, H, W, accumulate);
   FN2_CHECK_LAUNCH("upsample_flow_bwd");
   return FN2_OK;
 }
 
 int fn2_head_bwd_filter(const fn2_tensor* x, const float* g, float* dw, int cin_pad, int kpad, void* stream) {
   FN2_REQUIRE(x && x->data && g && dw, "head_bwd_filter: null pointer");
-  FN2_REQUIRE(x->dtype == FN2_F32 && cin_pad >= x->c && kpad >= 9 * cin_pad, "head_bwd_filter: bad layout");
+  FN2_REQUIRE((x->dtype == FN2_F32 || x->dtype == FN2_F16X2) && cin_pad >= x->c && kpad >= 9 * cin_pad, "head_bwd_filter: bad layout");
   FN2_REQUIRE(x->cs % 4 == 0 && x->c0 % 4 == 0 && (x->c + 3) / 4 * 4 <= x->cs - x->c0, "head_bwd_filter: x view must be 16-byte aligned and padded to 4 channels");
   const long npix = (long)x->n * x->h * x->w;
   int splits = (int)((npix + 511) / 512);
   if (splits > 512) splits = 512;
-  hipLaunchKernelGGL(head_bwd_filter_kernel, dim3((x->c + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)x->data, x->cs, x->c0, x->c, g, dw, cin_pad, kpad, x->n, x->h, x->w);
+  if (x->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(head_bwd_filter_kernel<x2_t>, dim3((x->c + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream,
+                       (const x2_t*)x->data, x->cs, x->c0, x->c, g, dw, cin_pad, kpad, x->n, x->h, x->w);
+  else
+    hipLaunchKernelGGL(head_bwd_filter_kernel<float>, dim3((x->c + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x->data, x->cs, x->c0, x->c, g, dw, cin_pad, kpad, x->n, x->h, x->w);
   FN2_CHECK_LAUNCH("head_bwd_filter");
   return FN2_OK;
 }
 
 int fn2_head_bwd_data(const float* g, const float* w, const fn2_tensor* dx, int cin_pad, int kpad, void* stream) {
   FN2_REQUIRE(g && w && dx && dx->data, "head_bwd_data: null pointer");
-  FN2_REQUIRE(dx->dtype == FN2_F32 && cin_pad >= dx->c && cin_pad % 4 == 0 && kpad >= 9 * cin_pad, "head_bwd_data: bad layout");
+  FN2_REQUIRE((dx->dtype == FN2_F32 || dx->dtype == FN2_F16X2) && cin_pad >= dx->c && cin_pad % 4 == 0 && kpad >= 9 * cin_pad,
+              "head_bwd_data: bad layout");
+  FN2_REQUIRE(dx->cs % 4 == 0 && dx->c0 % 4 == 0, "head_bwd_data: dx view must be 16-byte aligned");
   const long total = (long)dx->n * dx->h * dx->w * ((dx->c + 3) / 4);
-  hipLaunchKernelGGL(head_bwd_data_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g, w,
-                     (float*)dx->data, dx->cs, dx->c0, dx->c, cin_pad, kpad, dx->n, dx->h, dx->w);
+  if (dx->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(head_bwd_data_kernel<x2_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g, w,
+                       (x2_t*)dx->data, dx->cs, dx->c0, dx->c, cin_pad, kpad, dx->n, dx->h, dx->w);
+  else
+    hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g, w,
+                       (float*)dx->data, dx->cs, dx->c0, dx->c, cin_pad, kpad, dx->n, dx->h, dx->w);
   FN2_CHECK_LAUNCH("head_bwd_data");
   return FN2_OK;
 }
 
 int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   FN2_REQUIRE(d && d->x.data && d->dy.data && d->dw, "bwd_filter: null pointer");
-  FN2_REQUIRE(d->x.dtype == FN2_F32 && d->dy.dtype == FN2_F32, "bwd_filter: fp32 only");
+  FN2_REQUIRE((d->x.dtype == FN2_F32 || d->x.dtype == FN2_F16X2) && d->dy.dtype == d->x.dtype,
+              "bwd_filter: x and dy must both be fp32 or both split fp16");
+  if (d->x.dtype == FN2_F16X2)
+    FN2_REQUIRE(d->x.cs % 8 == 0 && d->x.c0 % 8 == 0 && d->dy.cs % 8 == 0 && d->dy.c0 % 8 == 0, "bwd_filter: split-fp16 views are group (8) aligned");
   FN2_REQUIRE(d->kind >= 0 && d->kind <= 2, "bwd_filter: kind 0 (conv), 1 (deconv k4 s2 crop 1) or 2 (stem row-run conv)");
   FN2_REQUIRE(d->x.n == d->dy.n, "bwd_filter: batch mismatch");
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cout_pad >= d->dy.c && d->kpad > 0, "bwd_filter: bad packed sizes");
@@ -648,7 +936,15 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   splits = (a.P + a.pix_per_split - 1) / a.pix_per_split;
   const dim3 grid(it, jt * taps, splits), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define FN2_BWF(SW_, NI_, NJ_) hipLaunchKernelGGL((bwd_filter_kernel<SW_, NI_, NJ_>), grid, block, 0, st, a)
+#define FN2_BWF(SW_, NI_, NJ_)                                                                       \
+  do {                                                                                               \
+    if (x2 && x2_mfma) hipLaunchKernelGGL((bwd_filter_x2_kernel<SW_, NI_, NJ_>), grid, block, 0, st, a); \
+    else if (x2) hipLaunchKernelGGL((bwd_filter_kernel<SW_, NI_, NJ_, true>), grid, block, 0, st, a);  \
+    else hipLaunchKernelGGL((bwd_filter_kernel<SW_, NI_, NJ_, false>), grid, block, 0, st, a);        \
+  } while (0)
+  const bool x2 = d->x.dtype == FN2_F16X2;
+  const char* dbg_env = getenv("FN2_CONV_DBG");
+  const bool x2_mfma = !(dbg_env && (atoi(dbg_env) & 128));  // bit 128: the fp32-MFMA form on split-fp16 tensors (A/B)
   if (d->kind == 1) {
     if (ni == 2 && nj == 2) FN2_BWF(true, 2, 2); else if (ni == 2) FN2_BWF(true, 2, 1);
     else if (nj == 2) FN2_BWF(true, 1, 2); else FN2_BWF(true, 1, 1);

@@ -70,10 +70,11 @@ PROTOTYPES = {
     "fn2_correlation_fused": (_i, [_tp, _tp, _tp, _i, _i, _i, _p]),
     "fn2_stack_input": (_i, [_p, _p, _p, _tp, _i, _p]),
     "fn2_fusion_input": (_i, [_p, _p, _p, _p, _tp, _i, _p]),
-    "fn2_epe_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "fn2_epe_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "fn2_leaky_bwd": (_i, [_tp, _tp, _p, _p]),
     "fn2_bias_grad": (_i, [_tp, _p, _p]),
     "fn2_gather_f32": (_i, [_p, _p, _p, C.c_int64, _p]),
+    "fn2_to_f16x2": (_i, [_p, _p, _p, C.c_int64, _f, _p]),
     "fn2_adam_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _i, _f, _f, _p]),
     "fn2_upsample_flow_bwd": (_i, [_tp, _p, _p, _p, _p, _i, _p]),
     "fn2_head_bwd_filter": (_i, [_tp, _p, _p, _i, _i, _p]),

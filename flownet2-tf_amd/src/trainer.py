@@ -51,8 +51,20 @@ def _index_hwio(rec):
 
 
 class FlowNetSTrainer:
-    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8):
-        self.eng = Engine("FlowNetS", weights, batch, height, width, "f32", heads_as_gemm=False)
+    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8, dtype="f32"):
+        """dtype 'f32': everything on the fp32 matrix cores.  'f16x2': activations, activation gradients and the
+        weight copies the convolutions read are split fp16 (3 fp16 MFMAs per product, fp32 accumulate); the master
+        weights, their gradients and the Adam state stay fp32."""
+        if dtype not in ("f32", "f16x2"):
+            raise ValueError("trainer dtype must be 'f32' or 'f16x2'")
+        self.x2 = dtype == "f16x2"
+        # loss scaling: activation gradients of this loss are 1e-4 .. 1e-7, under the fp16 normal range that the
+        # split (hi + lo) format needs for its lo parts; 2^14 brings them to O(1).  Linear, so every parameter
+        # gradient carries the same factor and Adam's grad_scale removes it exactly.
+        self.loss_scale = 16384.0 if self.x2 else 1.0
+        self.code = _hip.FN2_F16X2 if self.x2 else F32
+        self.host_weights = weights
+        self.eng = Engine("FlowNetS", weights, batch, height, width, dtype, heads_as_gemm=False)
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
         self.schedule, self.eps = schedule, eps
@@ -70,23 +82,47 @@ class FlowNetSTrainer:
             base = self.base_of[key]
             self.gbufs[key] = torch.zeros_like(base)
         g = self.gbufs[key]
+        self.gcode[g.data_ptr()] = self.eng._code(buf)
         if buf.shape[0] != g.shape[0]:  # batch slice of a 2N buffer (not used by FlowNetS)
             raise NotImplementedError
         return g
 
     def _view(self, buf, c, c0):
-        return _hip.view(buf, c, c0, F32)
+        """View of an activation / gradient buffer (fp32 buffers -- flow heads -- stay fp32 in every mode)."""
+        code = self.gcode.get(buf.data_ptr())
+        return _hip.view(buf, c, c0, code if code is not None else self.eng._code(buf))
+
+    def _master(self, rec):
+        """fp32 master of a layer's packed weight.  fp32 trainer: the tensor the forward reads.  f16x2 trainer: a
+        separate fp32 tensor in the same packed geometry (the forward reads a split-fp16 copy, refreshed per step)."""
+        if not self.x2 or rec["kind"] == "upflow" or rec["w"].dtype == torch.float32 and rec.get("cout") == 2:
+            return rec["w"]
+        name = f"{rec['scope']}/{rec['name']}/weights"
+        w = np.asarray(self.host_weights[name], np.float32)
+        if rec["kind"] == 1:
+            pk = W.pack_deconv(w, rec["tile"], rec["kstep"], rec["cin_pad"], rec["layout"])[0]
+        elif rec["kind"] == 2:
+            pk = W.pack_stem(w, rec["cs"], rec["cin_pad"], rec["tile"], rec["layout"])[0]
+        else:
+            pk = W.pack_conv(w, rec["tile"], rec["kstep"], rec["cin_pad"], rec["layout"])[0]
+        return torch.from_numpy(np.ascontiguousarray(pk, np.float32)).to(self.dev)
 
     def _build(self):
         eng = self.eng
         self.base_of = {b.untyped_storage().data_ptr(): b for b in eng.bufs.values()}
         self.gbufs = {}
+        self.gcode = {}  # gradient buffer -> fn2_dtype of the activation buffer it mirrors
         layers = eng.layers
         # ---- parameters and one flat gradient / moment arena (single all-reduce, single memset)
         params = []  # (tensor, l2 flag)
+        self.fwd_copies = []  # f16x2 trainer: (split-fp16 forward weight, fp32 master, scale)
         for rec in layers:
             reg = rec["kind"] in (0, 2)  # slim.conv2d weights (heads included); deconv / upsample / biases are not
-            params.append((rec["w"], reg, rec))
+            rec["master"] = self._master(rec)
+            if rec["master"] is not rec["w"]:
+                rec["scale"] = 1.0 / float(rec["desc"].out_scale)
+                self.fwd_copies.append((rec["w"], rec["master"], rec["scale"]))
+            params.append((rec["master"], reg, rec))
             if rec.get("b") is not None:
                 params.append((rec["b"], False, None))
         total = sum(_round_up(t.numel(), 4) for t, _, _ in params)
@@ -127,11 +163,12 @@ class FlowNetSTrainer:
         gy_buf, gy_c0, gy_c = g_src
         gx_buf, gx_c0, gx_c = g_dst
         cin_b, cout_b = gy_c, gx_c
+        code = self.code
         cin_pad = _round_up(cin_b, 8)
         line = _round_up(cin_b, 32)
-        if gy_c0 + line <= gy_buf.shape[3] and _hip.conv_plan(F32, line, cout_b).layout == 1:
+        if gy_c0 + line <= gy_buf.shape[3] and _hip.conv_plan(code, line, cout_b).layout == 1:
             cin_pad = line
-        plan = _hip.conv_plan(F32, cin_pad, cout_b)
+        plan = _hip.conv_plan(code, cin_pad, cout_b)
         enum = hwio_index.astype(np.float64) + 1.0
         if kind == 3:
             pk, cin_pad, cout_pad, kpad = W.pack_conv_transpose_s2(enum, pad, plan.cout_tile, plan.kstep_elems, cin_pad,
@@ -140,8 +177,9 @@ class FlowNetSTrainer:
             pk, cin_pad, cout_pad, kpad = W.pack_conv(enum, plan.cout_tile, plan.kstep_elems, cin_pad, plan.layout,
                                                       dtype=np.float64)
         gmap = torch.from_numpy((pk.reshape(-1) - 1.0).astype(np.int32)).to(self.dev)
-        wb = torch.zeros(gmap.numel(), dtype=torch.float32, device=self.dev)
-        self.gathers.append((wb, rec["w"], gmap))
+        wb = torch.zeros(gmap.numel(), dtype=torch.float32, device=self.dev)  # fp32, or split fp16 in an fp32 container
+        scale = rec.get("scale", 1.0)
+        self.gathers.append((wb, rec["master"], gmap, scale))
         d = _hip.Fn2ConvDesc()
         d.inp = self._view(gy_buf, gy_c, gy_c0)
         d.out = self._view(gx_buf, gx_c, gx_c0)
@@ -150,15 +188,16 @@ class FlowNetSTrainer:
         d.act = _hip.ACT_NONE
         d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, plan.layout
         d.accumulate = 1
-        d.out_scale = 1.0
+        d.out_scale = 1.0 / scale
         self.keep += [d, wb, gmap]
         self.eng.conv_descs.append(d)  # shares the split-K workspace
+        tn = "fn2::x2_t" if self.x2 else "float"
         if plan.layout == 1:
             from .engine import conv2_kernel_args
             gxs = gx_buf.shape
             m_px = gxs[0] * gxs[1] * gxs[2] // (4 if kind == 3 else 1)
-            d.kernel_name = "conv_igemm2_kernel<float, float, %s>" % conv2_kernel_args(plan.cout_tile, m_px, cout_pad,
-                                                                                       4 if kind == 3 else 1)
+            d.kernel_name = "conv_igemm2_kernel<%s, %s, %s>" % (tn, tn, conv2_kernel_args(plan.cout_tile, m_px, cout_pad,
+                                                                                               4 if kind == 3 else 1))
         else:
             d.kernel_name = "conv_igemm_kernel<float, float, %s>" % {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4",
                                                                       16: "1, 1, 4"}[plan.cout_tile]
@@ -211,7 +250,7 @@ class FlowNetSTrainer:
                (self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"])))]
         vdx = self._view(gx, sc, sc0)
         self.keep.append(vdx)
-        ops.append((self.lib.fn2_head_bwd_data, (_hip.ptr(dpf), _hip.ptr(rec["w"]), C.byref(vdx), rec["cin_pad"], rec["kpad"])))
+        ops.append((self.lib.fn2_head_bwd_data, (_hip.ptr(dpf), _hip.ptr(rec["master"]), C.byref(vdx), rec["cin_pad"], rec["kpad"])))
         self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
 
     def _plan_upflow(self, rec):
@@ -233,15 +272,22 @@ class FlowNetSTrainer:
                 if fn is self.lib.fn2_conv2d:
                     fl, kern = flops.get(name, 0.0), args[0]._obj.kernel_name
                 elif fn is self.lib.fn2_conv2d_bwd_filter:
-                    fl, kern = flops.get(name, 0.0), "bwd_filter_kernel"
+                    fl, kern = flops.get(name, 0.0), ("bwd_filter_x2_kernel" if self.x2 else "bwd_filter_kernel")
                 out.append(("bwd " + name, fn, args, kern, fl))
         return out
 
     # ------------------------------------------------------------------ step
     def refresh_backward_weights(self):
+        """Derive every weight copy the convolutions read from the fp32 masters: the transposed / phase-decomposed
+        layouts of the input-gradient convolutions and, in the f16x2 trainer, the split-fp16 forward weights."""
         s = _hip.stream_ptr()
-        for wb, wsrc, gmap in self.gathers:
-            _hip.check(self.lib.fn2_gather_f32(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), s))
+        for wb, wsrc, gmap, scale in self.gathers:
+            if self.x2:
+                _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), scale, s))
+            else:
+                _hip.check(self.lib.fn2_gather_f32(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), s))
+        for wx2, master, scale in self.fwd_copies:
+            _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wx2), _hip.ptr(master), None, master.numel(), scale, s))
 
     def learning_rate(self, step):
         lr = self.schedule["learning_rates"]
@@ -268,7 +314,7 @@ class FlowNetSTrainer:
             label = torch.empty_like(pred)
             _hip.check(self.lib.fn2_downsample_f32(_hip.ptr(gts), _hip.ptr(label), n, self.H, self.W, 2, h, w, s))
             _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
-                                                  _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, s))
+                                                  _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, self.loss_scale, s))
             self.keep_label = label
         # ---- backward
         for name, ops in self.bwd_ops:
@@ -299,7 +345,7 @@ class FlowNetSTrainer:
         for p in self.params:
             _hip.check(self.lib.fn2_adam_step(_hip.ptr(p["w"]), _hip.ptr(p["m"]), _hip.ptr(p["v"]), _hip.ptr(p["g"]),
                                               p["n"], lr, b1, b2, self.eps, self.step_count,
-                                              l2 if p["reg"] else 0.0, 1.0 / world, s))
+                                              l2 if p["reg"] else 0.0, 1.0 / (world * self.loss_scale), s))
         self.refresh_backward_weights()
 
     def train_step(self, input_a, input_b, gt_flow):

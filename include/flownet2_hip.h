@@ -218,14 +218,20 @@ int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const
  * kind 0 k4 s2 for the transposed convs) with `accumulate`. */
 
 /* L = weight * sum_pixels ||pred - label||_2 / n added to *loss_accum (device scalar);
- * dpred = weight / n * (pred - label) / ||pred - label||  (average_endpoint_error, utils.py:209-224). */
+ * dpred = grad_mult * weight / n * (pred - label) / ||pred - label||  (average_endpoint_error, utils.py:209-224).
+ * grad_mult: loss scaling of the split-fp16 trainer (a power of two that keeps the activation gradients inside
+ * the fp16 exponent range; removed again by fn2_adam_step's grad_scale), 1 otherwise. */
 int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float* loss_accum, int n, int h, int w,
-                      float weight, void* stream);
+                      float weight, float grad_mult, void* stream);
 /* g *= LeakyReLU'(.) evaluated from the layer output y (utils.py:401-405); y, g fp32 channel-slice views.
  * db != NULL: the bias gradient of the same layer in the same pass, db[c] += sum over pixels of the new g. */
 int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* stream);
 /* db[c] += sum over pixels of g (db zeroed by the caller). */
 int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream);
+/* dst (split fp16, n logical elements, n % 8 == 0) = scale * (map ? src[map[i]] (0 where map[i] < 0) : src[i]): the
+ * forward and backward-data weight copies of the split-fp16 trainer, re-derived from the fp32 master every step
+ * (scale = the power of two of the layer's descriptor, out_scale = 1 / scale). */
+int fn2_to_f16x2(void* dst, const float* src, const int32_t* map, int64_t n, float scale, void* stream);
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0: derives the weight layouts of the input-gradient convolutions. */
 int fn2_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, void* stream);
 /* tf.train.AdamOptimizer update of n parameters with g' = grad_scale*g + l2*w (slim l2_regularizer). */

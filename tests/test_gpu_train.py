@@ -24,7 +24,11 @@ def device_signs(tr):
     for rec in tr.eng.layers:
         if rec["kind"] != "upflow" and rec["act"]:
             buf, c0, c = rec["dst"]
-            out[rec["name"]] = (buf[..., c0:c0 + c] > 0).cpu().numpy()
+            vals = buf.cpu().numpy()
+            if tr.x2:  # split-fp16 activations live in fp32 containers: (hi, lo) halves per 8-channel group
+                from src import weights as W
+                vals = W.join_f16x2(vals.view(np.float16))
+            out[rec["name"]] = vals[..., c0:c0 + c] > 0
     return out
 
 
@@ -63,12 +67,13 @@ def test_oracle_torch_forward_equals_numpy_forward():
 
 
 @pytest.mark.gpu
-def test_flownet_s_gradients_match_oracle():
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_flownet_s_gradients_match_oracle(dtype):
     from src import weights as W
     from src.trainer import FlowNetSTrainer
     wts = W.init_weights("FlowNetS", 5)
     a, b, gt = data(2, 128, 192, 1)
-    tr = FlowNetSTrainer(wts, 2, 128, 192)
+    tr = FlowNetSTrainer(wts, 2, 128, 192, dtype=dtype)
     loss = float(tr.forward_backward(a, b, gt).item())
     signs, pre = device_signs(tr), {}
     want_loss, grads, _ = reft.flownet_s_loss_and_grads(wts, a, b, gt, signs=signs, act_grads=pre)
@@ -77,7 +82,7 @@ def test_flownet_s_gradients_match_oracle():
     worst = 0.0
     for rec in tr.eng.layers:
         name = f"{rec['scope']}/{rec['name']}"
-        got = rec["dw"].cpu().numpy()
+        got = rec["dw"].cpu().numpy() / np.float32(tr.loss_scale)
         if rec["kind"] == "upflow":
             want = grads[name + "/weights"].astype(np.float32).reshape(-1)
         else:
@@ -86,7 +91,7 @@ def test_flownet_s_gradients_match_oracle():
         err = np.abs(got - want).max() / scale
         berr = 0.0
         if rec.get("b") is not None:
-            gb, wb = rec["db"].cpu().numpy(), grads[name + "/biases"]
+            gb, wb = rec["db"].cpu().numpy() / np.float32(tr.loss_scale), grads[name + "/biases"]
             berr = np.abs(gb - wb).max() / (np.abs(wb).max() + 1e-12)
         print("  %-28s filter %.2e  bias %.2e" % (name, err, berr))
         worst = max(worst, err, berr)
@@ -95,12 +100,13 @@ def test_flownet_s_gradients_match_oracle():
 
 
 @pytest.mark.gpu
-def test_adam_steps_match_oracle():
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_adam_steps_match_oracle(dtype):
     from src import weights as W
     from src.trainer import FlowNetSTrainer
     wts = W.init_weights("FlowNetS", 6)
     a, b, gt = data(1, 128, 128, 2)
-    tr = FlowNetSTrainer(wts, 1, 128, 128)
+    tr = FlowNetSTrainer(wts, 1, 128, 128, dtype=dtype)
     cur = {k: np.asarray(v, np.float64) for k, v in wts.items()}
     mom = {k: (np.zeros_like(v), np.zeros_like(v)) for k, v in cur.items()}
     l2 = tr.schedule["l2_regularization"]
@@ -115,14 +121,22 @@ def test_adam_steps_match_oracle():
             mom[k] = (m, v)
     for rec in tr.eng.layers:
         name = f"{rec['scope']}/{rec['name']}/weights"
-        got = rec["w"].cpu().numpy().reshape(-1)
+        got = rec["master"].cpu().numpy().reshape(-1)
         want = cur[name].astype(np.float32)
         want = want.reshape(-1) if rec["kind"] == "upflow" else packed_grad(rec, want).reshape(-1)
         # two Adam steps move every weight by ~2e-4; compare the MOVEMENT, not the value
         w0 = np.asarray(wts[name], np.float32)
         w0 = w0.reshape(-1) if rec["kind"] == "upflow" else packed_grad(rec, w0).reshape(-1)
         move_got, move_want = got - w0, want - w0
-        assert np.abs(move_got - move_want).max() < 0.05 * np.abs(move_want).max(), name
+        diff = np.abs(move_got - move_want)
+        if dtype == "f32":
+            assert diff.max() < 0.05 * np.abs(move_want).max(), name
+        else:
+            # Adam's first steps move a weight by ~ -lr * sign(g + l2 w): an element whose regularised gradient is
+            # within the gradient noise of zero (1e-6 of the layer maximum with split-fp16 operands, 10x the fp32
+            # trainer's) can step the other way.  Bound their share; everything else must agree.
+            bad = diff > 0.05 * np.abs(move_want).max()
+            assert bad.mean() < 1e-2 and np.median(diff) < 1e-3 * np.abs(move_want).max(), (name, bad.mean())
 
 
 def _dp_worker(rank, world, port, out_path):
@@ -141,7 +155,7 @@ def _dp_worker(rank, world, port, out_path):
     tr = FlowNetSTrainer(W.init_weights("FlowNetS", 7), hi - lo, 128, 128)
     tr.forward_backward(a[lo:hi], b[lo:hi], gt[lo:hi])
     n = allreduce_gradients(tr.grad_arena)
-    grads = (tr.grad_arena / n).cpu().numpy()
+    grads = (tr.grad_arena / (n * tr.loss_scale)).cpu().numpy()
     tr.apply_gradients(reduced_world=n)
     tr.train_step(a[lo:hi], b[lo:hi], gt[lo:hi])
     if rank == 0:
@@ -163,7 +177,7 @@ def test_two_rank_data_parallel_equals_full_batch(tmp_path):
     tr = FlowNetSTrainer(W.init_weights("FlowNetS", 7), 2, 128, 128)
     w0 = torch.cat([p["w"].reshape(-1) for p in tr.params]).cpu().numpy()
     tr.forward_backward(a, b, gt)
-    want_g = tr.grad_arena.cpu().numpy()
+    want_g = (tr.grad_arena / tr.loss_scale).cpu().numpy()
     tr.apply_gradients()
     tr.train_step(a, b, gt)
     want_w = torch.cat([p["w"].reshape(-1) for p in tr.params]).cpu().numpy()
