@@ -736,6 +736,15 @@ int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float
   return FN2_OK;
 }
 
+// pixel ranges per channel block: <= 512 blocks (each ends with same-address atomics on db), but never fewer than
+// ~16 pixels per thread row, so that small tensors still spread over the chip
+static int bias_splits(long npix, int gpb_log2) {
+  const int rows = 256 >> gpb_log2;
+  long s = npix / (rows * 8 > 16 ? rows * 8 : 16);
+  if (s > 512) s = 512;
+  return (int)(s < 1 ? 1 : s);
+}
+
 static int gpb_log2_for(int c4) {
   int l = 0;
   while ((1 << l) < c4 && l < 8) ++l;
@@ -751,8 +760,7 @@ int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* str
                 "leaky_bwd: split-fp16 slices are group (8) aligned");
     const long npx = (long)y->n * y->h * y->w;
     const int l2x = gpb_log2_for(y->c / 8);
-    long sp = (npx + 255) / 256;
-    if (sp > 512) sp = 512;
+    const int sp = bias_splits(npx, l2x);
     hipLaunchKernelGGL(act_bias_bwd_x2_kernel<true>, dim3((y->c / 8 + (1 << l2x) - 1) >> l2x, (int)sp), dim3(256), 0,
                        (hipStream_t)stream, (const x2_t*)y->data, (x2_t*)g->data, db, npx, y->c, y->cs, y->c0, g->cs,
                        g->c0, l2x);
@@ -765,8 +773,7 @@ int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* str
   const int l2 = gpb_log2_for(y->c / 4);
   // few, fat blocks: every block ends with one atomic per channel on the SAME db[c] addresses, and 2048 blocks
   // serialised on them cost more than the pass itself (conv1: 0.22 ms for a 300 MB pass)
-  long splits = (npix + 255) / 256;
-  if (splits > 512) splits = 512;
+  const int splits = bias_splits(npix, l2);
   hipLaunchKernelGGL(act_bias_bwd_kernel<true>, dim3((y->c / 4 + (1 << l2) - 1) >> l2, (int)splits), dim3(256), 0,
                      (hipStream_t)stream, (const float*)y->data, (float*)g->data, db, npix, y->c, y->cs, y->c0, g->cs,
                      g->c0, l2);
@@ -783,8 +790,7 @@ int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream) {
     hipLaunchKernelGGL(bias_grad2_kernel, dim3(grid_for(npix, 1024)), dim3(256), 0, st, (const float*)g->data, db, npix);
   } else if (g->c % 4 == 0 && g->cs % 4 == 0 && g->c0 % 4 == 0) {
     const int l2 = gpb_log2_for(g->c / 4);
-    long splits = (npix + 255) / 256;
-    if (splits > 512) splits = 512;
+    const int splits = bias_splits(npix, l2);
     hipLaunchKernelGGL(act_bias_bwd_kernel<false>, dim3((g->c / 4 + (1 << l2) - 1) >> l2, (int)splits), dim3(256), 0, st,
                        (const float*)nullptr, (float*)g->data, db, npix, g->c, 0, 0, g->cs, g->c0, l2);
   } else {
