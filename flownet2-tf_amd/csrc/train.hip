@@ -125,22 +125,46 @@ __global__ void __launch_bounds__(256) act_bias_bwd_x2_kernel(const x2_t* __rest
   const long per = (npix + gridDim.y - 1) / gridDim.y;
   const long p0 = (long)blockIdx.y * per, p1 = min(npix, p0 + per);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (ch < c)
-    for (long pix = p0 + tr; pix < p1; pix += rows) {
-      uint4* gp = reinterpret_cast<uint4*>(g + pix * g_cs + g_c0 + ch);
+  if (ch < c) {
+    auto one = [&](uint4* gp, const uint4 (&gq)[2], const uint4 (&yq)[2]) {
       float gv[8];
-      join8(gp[0], gp[1], gv);
+      join8(gq[0], gq[1], gv);
       if constexpr (ACT) {
-        const uint4* yp = reinterpret_cast<const uint4*>(y + pix * y_cs + y_c0 + ch);
         float yv[8];
-        join8(yp[0], yp[1], yv);
+        join8(yq[0], yq[1], yv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) gv[j] *= yv[j] > 0.f ? 1.f : (yv[j] < 0.f ? 0.1f : 0.55f);
         split8(gv, gp[0], gp[1]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += gv[j];
+    };
+    long pix = p0 + tr;
+    for (; pix + 3L * rows < p1; pix += 4L * rows) {  // four pixels per trip: 16 x 16-byte loads in flight per lane
+      uint4 gq[4][2], yq[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint4* gp = reinterpret_cast<const uint4*>(g + (pix + (long)u * rows) * g_cs + g_c0 + ch);
+        gq[u][0] = gp[0]; gq[u][1] = gp[1];
+        if constexpr (ACT) {
+          const uint4* yp = reinterpret_cast<const uint4*>(y + (pix + (long)u * rows) * y_cs + y_c0 + ch);
+          yq[u][0] = yp[0]; yq[u][1] = yp[1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        one(reinterpret_cast<uint4*>(g + (pix + (long)u * rows) * g_cs + g_c0 + ch), gq[u], yq[u]);
     }
+    for (; pix < p1; pix += rows) {
+      uint4* gp = reinterpret_cast<uint4*>(g + pix * g_cs + g_c0 + ch);
+      uint4 gq[2] = {gp[0], gp[1]}, yq[2] = {gq[0], gq[1]};
+      if constexpr (ACT) {
+        const uint4* yp = reinterpret_cast<const uint4*>(y + pix * y_cs + y_c0 + ch);
+        yq[0] = yp[0]; yq[1] = yp[1];
+      }
+      one(gp, gq, yq);
+    }
+  }
   if (db == nullptr) return;
   __shared__ float s[256][9];
 #pragma unroll
