@@ -49,3 +49,22 @@ def allreduce_gradients(flat):
     else:
         dist.all_reduce(flat)
     return dist.get_world_size()
+
+
+def allreduce_bucket_async(bucket):
+    """Start the SUM of one contiguous slice of the gradient arena; returns a handle with .wait() (None when
+    there is nothing to wait for).  Called from inside the backward pass as soon as the slice is complete, so
+    the ring runs on RCCL's stream under the remaining backward kernels (c10d orders it after the producing
+    kernels of the current stream)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    if bucket.is_cuda and dist.get_backend() == "gloo":  # CPU-rendezvous tests: synchronous staging
+        host = bucket.cpu()
+        dist.all_reduce(host)
+        bucket.copy_(host)
+        return None
+    return dist.all_reduce(bucket, async_op=True)
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1

@@ -156,6 +156,30 @@ class FlowNetSTrainer:
                 self._plan_conv(rec)
         eng._alloc_workspace()  # the input-gradient convolutions share the split-K scratch buffer
         self.refresh_backward_weights()
+        self._plan_buckets(4)
+
+    def _plan_buckets(self, n_buckets):
+        """Gradient exchange overlapped with backward: the arena is laid out in FORWARD layer order and backward
+        completes it from the tail, so a bucket is a contiguous tail slice; it is reduced as soon as the backward
+        of its first (earliest-forward) layer has been enqueued.  ~40 MB buckets keep the xGMI ring
+        bandwidth-bound.  self.buckets[i] = (index into bwd_ops after which it is complete, arena slice)."""
+        offs, off = {}, 0
+        for rec in self.eng.layers:
+            lo = off
+            off += _round_up(rec["master"].numel(), 4)
+            if rec.get("b") is not None:
+                off += _round_up(rec["b"].numel(), 4)
+            offs[f"{rec['scope']}/{rec['name']}"] = (lo, off)
+        total, target = off, off / float(n_buckets)
+        self.buckets, hi, acc = [], total, 0
+        for i, (name, _) in enumerate(self.bwd_ops):
+            lo, _hi = offs[name]
+            acc = hi - lo
+            last = i == len(self.bwd_ops) - 1
+            if acc >= target or last:
+                self.buckets.append((i, self.grad_arena[lo:hi]))
+                hi = lo
+        assert hi == 0 and sum(b.numel() for _, b in self.buckets) == total
 
     def _bwd_data_conv(self, rec, hwio_index, kind, k, stride, pad, g_src, g_dst):
         """fn2_conv2d launch computing the input gradient: in = gradient of the layer output slice,
@@ -296,8 +320,10 @@ class FlowNetSTrainer:
                 return lr[i]
         return lr[-1]
 
-    def forward_backward(self, input_a, input_b, gt_flow):
-        """Loss and all parameter gradients (left in self.grad_arena).  Returns the loss as a device scalar."""
+    def forward_backward(self, input_a, input_b, gt_flow, reduce=False):
+        """Loss and all parameter gradients (left in self.grad_arena).  Returns the loss as a device scalar.
+        reduce=True: every gradient bucket is all-reduced as soon as backward has produced it (overlap);
+        finish with apply_gradients(reduced_world=...) / wait_reduction()."""
         eng, s = self.eng, _hip.stream_ptr()
         self.gt.copy_(torch.as_tensor(gt_flow).to(dtype=torch.float32), non_blocking=True)
         eng.set_inputs(input_a, input_b)
@@ -317,7 +343,9 @@ class FlowNetSTrainer:
                                                   _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, self.loss_scale, s))
             self.keep_label = label
         # ---- backward
-        for name, ops in self.bwd_ops:
+        from .dist import allreduce_bucket_async
+        self._pending, nb = [], 0
+        for i, (name, ops) in enumerate(self.bwd_ops):
             for fn, args in ops:
                 rc = fn(*args, s)
                 if rc:
@@ -325,7 +353,20 @@ class FlowNetSTrainer:
                         _hip.check(rc)
                     except Exception as e:
                         raise type(e)("backward of %s: %s" % (name, e)) from None
+            if reduce and nb < len(self.buckets) and self.buckets[nb][0] == i:
+                h = allreduce_bucket_async(self.buckets[nb][1])
+                if h is not None:
+                    self._pending.append(h)
+                nb += 1
         return self.loss_dev
+
+    def wait_reduction(self):
+        """Block the compute stream on the outstanding bucket all-reduces; returns the number of ranks summed."""
+        from .dist import world_size
+        for h in getattr(self, "_pending", []):
+            h.wait()
+        self._pending = []
+        return world_size()
 
     def l2_term(self):
         """0.5*l2*sum |W|^2 over the regularised weights (host-side report only)."""
@@ -349,6 +390,6 @@ class FlowNetSTrainer:
         self.refresh_backward_weights()
 
     def train_step(self, input_a, input_b, gt_flow):
-        loss = self.forward_backward(input_a, input_b, gt_flow)
-        self.apply_gradients()
+        loss = self.forward_backward(input_a, input_b, gt_flow, reduce=True)
+        self.apply_gradients(reduced_world=self.wait_reduction())
         return loss

@@ -157,7 +157,8 @@ def _dp_worker(rank, world, port, out_path):
     n = allreduce_gradients(tr.grad_arena)
     grads = (tr.grad_arena / (n * tr.loss_scale)).cpu().numpy()
     tr.apply_gradients(reduced_world=n)
-    tr.train_step(a[lo:hi], b[lo:hi], gt[lo:hi])
+    assert len(tr.buckets) >= 2 and sum(bk.numel() for _, bk in tr.buckets) == tr.grad_arena.numel()
+    tr.train_step(a[lo:hi], b[lo:hi], gt[lo:hi])  # second step: bucketed reduction inside backward
     if rank == 0:
         np.savez(out_path, grads=grads, weights=torch.cat([p["w"].reshape(-1) for p in tr.params]).cpu().numpy())
     dist.barrier()

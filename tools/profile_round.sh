@@ -24,7 +24,8 @@ stats flownetc_b8_f16x2 --steps 30 --warmup 5
 stats flownetc_b8_bf16 --steps 30 --warmup 5 --dtype bf16
 stats flownetc_b8_f32 --steps 30 --warmup 5 --dtype f32
 stats flownet2_b4_f16x2 --model FlowNet2 --batch 4 --steps 20 --warmup 3
-stats flownets_train_b8_f32 --mode train --steps 10 --warmup 3
+stats flownets_train_b8_f16x2 --mode train --steps 10 --warmup 3
+stats flownets_train_b8_f32 --mode train --train-dtype f32 --steps 10 --warmup 3
 
 pmc() {  # name, counter, bench args...
   local name=$1 counter=$2; shift 2
@@ -50,5 +51,6 @@ python $root/bench.py --steps 30 --warmup 5 > $out/${tag}_flownetc_b8_f16x2_benc
 python $root/bench.py --model FlowNet2 --batch 4 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_flownet2_b4_f16x2_bench.json 2> /dev/null
 python $root/bench.py --model FlowNet2 --batch 4 --height 448 --width 1024 --steps 10 --warmup 3 --no-cpu-baseline \
     > $out/${tag}_flownet2_b4_1024x448_f16x2_bench.json 2> /dev/null
-python $root/bench.py --mode train --steps 10 --warmup 3 > $out/${tag}_flownets_train_b8_f32_bench.json 2> /dev/null
+python $root/bench.py --mode train --steps 10 --warmup 3 > $out/${tag}_flownets_train_b8_f16x2_bench.json 2> /dev/null
+python $root/bench.py --mode train --train-dtype f32 --steps 10 --warmup 3 > $out/${tag}_flownets_train_b8_f32_bench.json 2> /dev/null
 ls -la $out
