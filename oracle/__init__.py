@@ -25,4 +25,11 @@ Pinning status (see DESIGN.md "Oracle"):
     arithmetic lives in TensorFlow 1.x + cuDNN (not vendored, not installed)
     => PARITY UNPINNED; the restatement of the TF op definitions is
     cross-checked against torch's CPU kernels as an independent implementation.
+  * ``train`` (FlowNetS loss gradients by torch float64 autograd over the restated graph, TF-form Adam): same
+    status as ``models`` => PARITY UNPINNED; its torch forward is tested against the NumPy forward to 1e-9.
+  * ``augment`` (DataAugmentation / FlowAugmentation of the preprocessing plugin): the plugin needs TensorFlow
+    headers to build and has no known-answer vectors => PARITY UNPINNED; two forms (vectorised, literal loops)
+    checked against each other plus identity / inverse properties.
+  * The MPI-Sintel metric code has no oracle copy: the product's ``src/flowlib.py`` is tested directly against
+    outputs of the reference's own functions (tests/golden/make_golden_metrics.py -> metrics_golden.npz): PINNED.
 """
