@@ -301,3 +301,36 @@ def test_conv_rejects_bad_descriptors():
     assert lib.fn2_conv2d(C.byref(d), None) == _hip.ERR_INVALID_ARGUMENT
     with pytest.raises(ValueError):
         _hip.check(lib.fn2_conv2d(C.byref(d), None))
+
+
+def _random_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        k = int(rng.choice([1, 3, 5]))
+        s = int(rng.choice([1, 2])) if k > 1 else 1
+        cin = int(rng.choice([32, 64, 96, 160, 224, 386]))
+        cout = int(rng.choice([8, 18, 32, 48, 64, 100, 128, 192, 320]))
+        H, Wd = int(rng.integers(5, 40)), int(rng.integers(5, 70))
+        cases.append((k, s, k // 2, cin, cout, H, Wd))
+    return cases
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_conv_random_shapes_cover_every_tile_variant(dtype):
+    """Ragged pixel counts (M not a multiple of any tile), channel counts that are not multiples of the cout
+    tile, odd stage counts and split-K on every block-tile instantiation of the LDS-DMA kernel."""
+    for i, (k, s, p, cin, cout, H, Wd) in enumerate(_random_cases(123, 14)):
+        N = 1 + i % 3
+        x = rnd((N, H, Wd, cin), 100 + i)
+        w = rnd((k, k, cin, cout), 200 + i, (2.0 / (k * k * cin)) ** 0.5)
+        b = rnd((cout,), 300 + i, 0.1)
+        want = refnn.conv2d(x, w, b, stride=s, padding=p, activation=refnn.leaky_relu)
+        got = run_conv(x, w, b, "conv", k, s, p, True, dtype, cout_off=8 if cout % 8 == 0 else 0, extra_out=8)
+        np.testing.assert_allclose(got, want, rtol=3e-5, atol=3e-5, err_msg=str((k, s, cin, cout, H, Wd, N)))
+    for i, (cin, cout, H, Wd) in enumerate([(96, 32, 7, 9), (224, 64, 5, 33), (386, 128, 9, 6), (64, 200, 12, 20)]):
+        x = rnd((2, H, Wd, cin), 400 + i)
+        w = rnd((4, 4, cout, cin), 500 + i, (2.0 / (4 * cin)) ** 0.5)
+        want = refnn.conv2d_transpose(x, w, activation=refnn.leaky_relu)
+        got = run_conv(x, w, None, "deconv", 4, 2, 1, True, dtype, cout_off=8)
+        np.testing.assert_allclose(got, want, rtol=3e-5, atol=3e-5, err_msg=str((cin, cout, H, Wd)))
