@@ -618,13 +618,15 @@ static bool is_flow_head(const fn2_conv_desc* d) {
 // of two.  Measured (tools/ab_conv.py, tools/ab_e2e.sh on one box): large 128-cout layers +1..13 % (the extra
 // resident block covers more of the DMA / barrier waits than the extra weight fetches cost), 24x32 / 12x16 levels
 // +17-19 % (no split-K slabs, no finalize launch), 64- and 32-cout layers +10..17 %; FlowNetC b8 -3.5 %,
-// FlowNet2 b4 -8 % end to end.  Exception: 128-cout layers whose half-width grid is still under 192 blocks (the 6x8
-// level) -- there the split-K count is what matters and the narrow tile loses 10 %.  FN2_CONV_DBG bit 32 = the
+// FlowNet2 b4 -8 % end to end.  Exception: 128-cout layers whose half-width grid is still under 96 blocks (the 6x8
+// level) -- there the split-K count is what matters and the narrow tile loses 10 % (at 12x16, 96 blocks: +14 %).  FN2_CONV_DBG bit 32 = the
 // full-width tiles (A/B).
 static bool wants_bp64(const ConvArgs& a, int tile, int phases, int layout) {
   if (layout != 1 || (a.dbg & 32)) return false;
   if (tile < 128) return true;
-  return cdiv(a.M, 64) * (long)(a.cout_pad / 128) * phases >= 192;
+  const char* e = getenv("FN2_BP64_MIN");  // tuning knob of the experiments behind the default
+  const int min_blocks = e ? atoi(e) : 96;
+  return cdiv(a.M, 64) * (long)(a.cout_pad / 128) * phases >= min_blocks;
 }
 
 // validate + fill everything except the split-K fields
@@ -736,6 +738,9 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     a.in_bytes = (int)in_bytes;
   }
   a.bp64 = wants_bp64(a, tile, phases, d->wgt_layout) ? 1 : 0;
+  // experiment (bit 64): weight-streaming 128-cout layers (the ones left on 128 x 128 + split-K) on 128 x 64 tiles
+  // with the 3-slot ring
+  if ((a.dbg & 64) && d->wgt_layout == 1 && tile == 128 && !a.bp64) a.bp64 = 2;
   *tile_out = tile;
   *phases_out = phases;
   return FN2_OK;
@@ -747,7 +752,11 @@ static int preferred_split(const ConvArgs& a, int tile, int phases) {
   const int bp = tile == 128 ? (a.bp64 ? 64 : 128) : (a.bp64 ? 128 : 256);
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
   if (blocks >= 384) return 1;
-  int s = (int)((512 + blocks - 1) / blocks);
+  // as many splits as still give ONE round of resident blocks (2-3 per CU): rounding up put 528 blocks on 512
+  // slots for the 12x16-level layers and a second round of 16 stragglers doubled the kernel time
+  const char* e = getenv("FN2_SPLIT_SLOTS");  // tuning knob of the experiments behind the default
+  const int slots = e ? atoi(e) : 512;
+  int s = (int)(slots / blocks);
   const int maxs = a.ksteps / 8;
   if (s > maxs) s = maxs;
   if (s > 16) s = 16;

@@ -63,7 +63,10 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
 // Cout <= 32 layers -- full-resolution fusion layers, conv_redir -- whose 64-cout tile was half or more padding).
 // TPN = 32-pixel MFMA tiles per wave (1: a 128-cout x 64-pixel block for mid-size layers whose 128 x 128 grid
 // would not fill the chip: twice the blocks instead of split-K slabs + a finalize launch).
-template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2>
+// STAGES = 3: a 3-slot LDS ring with the DMA TWO stages ahead, for the weight-streaming layers (6x8 / 12x16
+// levels): there every stage waits a full HBM round trip for weights nobody has touched yet, and one stage of
+// look-ahead per block leaves the chip latency-bound (conv6_1: 38 MB of weights in 46 us).
+template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2>
 __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
@@ -79,6 +82,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   // i.e. the "prefetch" of stage s+1 was waited for BEFORE the MFMAs of stage s.
   __shared__ uint4 lds0[ROWS * 8];
   __shared__ uint4 lds1[ROWS * 8];
+  __shared__ uint4 lds2[STAGES == 3 ? ROWS * 8 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,21 +280,44 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   // Two stages per trip so that every LDS access names its object statically (see the lds0/lds1 note), and no
   // branch between them: an odd stage count is rounded up with a stage whose pixel rows are all zero (the
   // validity test in issue_piece fails for stages >= kt1), so its MFMAs add 0 * stale finite weights.
-  // (Measured and dropped: a 3-slot ring with the DMA two stages ahead.  96 KB of LDS = one block per CU, and
-  // losing the second block's MFMAs under this block's waits cost 20-30% on every layer, bf16 and split fp16.)
-  issue_stage(lds0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int nst2 = (kt1 - kt0 + 1) & ~1;
-  for (int s = 0; s < nst2; s += 2) {
-    issue_stage(lds1);  // next stage's DMA in flight under this stage's MFMAs
-    compute(lds0);
+  if constexpr (STAGES == 2) {
+    // (On the MFMA-bound layers a 3-slot ring was measured 20-30 % slower with 128 x 128 tiles: 96 KB of LDS = one
+    // block per CU, and losing the second block's MFMAs under this block's waits costs more than the deeper
+    // prefetch gains.)
+    issue_stage(lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (s + 2 < nst2) issue_stage(lds0);
-    compute(lds1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const int nst2 = (kt1 - kt0 + 1) & ~1;
+    for (int s = 0; s < nst2; s += 2) {
+      issue_stage(lds1);  // next stage's DMA in flight under this stage's MFMAs
+      compute(lds0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 2 < nst2) issue_stage(lds0);
+      compute(lds1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // Ring: per stage, wait until all but the newest stage's ND DMA instructions of this wave have landed, bare
+    // s_barrier (every wave's rows of stage s are in LDS, and every wave is done reading slot (s+2)%3, the slot of
+    // stage s-1: its ds_reads were consumed by MFMAs before the barrier), refill that slot two stages ahead.
+    // __syncthreads() would not do: its fence drains vmcnt to 0, i.e. waits for the look-ahead stage as well.
+    constexpr int ND = NWI + NPI;
+    static_assert(ND == 6 || ND == 8, "vmcnt literal below");
+    auto ring_sync = [] {
+      if constexpr (ND == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    };
+    issue_stage(lds0);
+    issue_stage(lds1);
+    const int nst3 = (kt1 - kt0 + 2) / 3 * 3;
+    for (int s = 0; s < nst3; s += 3) {
+      ring_sync(); issue_stage(lds2); compute(lds0);
+      ring_sync(); issue_stage(lds0); compute(lds1);
+      ring_sync(); issue_stage(lds1); compute(lds2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead stages (all-zero pixel rows past kt1)
   }
 
   // ---- epilogue.  Lane (pixel fr of tile tp, half fh) holds couts [16 fh, 16 fh + 16) of cout tile tc.
@@ -359,7 +386,10 @@ template <typename T, typename OutT>
 static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   dim3 block(256);
   const int z = phases * a.splitk;
-  if (tile == 128 && a.bp64) {
+  if (tile == 128 && a.bp64 == 2) {
+    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1, 3>), grid, block, 0, s, a);
+  } else if (tile == 128 && a.bp64) {
     dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1>), grid, block, 0, s, a);
   } else if (tile == 128) {

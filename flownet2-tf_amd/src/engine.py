@@ -39,7 +39,7 @@ def conv2_kernel_args(tile, m, cout_pad, phases):
         return _TILE_ARGS[tile]
     if tile < 128:
         return {64: "1, 4, 2, 1", 32: "1, 4, 1, 1"}[tile]
-    if -(-m // 64) * (cout_pad // 128) * phases >= 192:
+    if -(-m // 64) * (cout_pad // 128) * phases >= int(os.environ.get("FN2_BP64_MIN", "96")):
         return "2, 2, 2, 1"
     return _TILE_ARGS[tile]
 

@@ -22,7 +22,11 @@ LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch
     "conv3": ("conv", 5, 2, 2, 128, 256, 8, 96, 128),
     "conv3_1": ("conv", 3, 1, 1, 256, 256, 8, 48, 64),
     "conv4_1": ("conv", 3, 1, 1, 512, 512, 8, 24, 32),
+    "conv5_1": ("conv", 3, 1, 1, 512, 512, 8, 12, 16),
+    "conv6": ("conv", 3, 2, 1, 512, 1024, 8, 12, 16),
     "conv6_1": ("conv", 3, 1, 1, 1024, 1024, 8, 6, 8),
+    "deconv5": ("deconv", 4, 2, 1, 1024, 512, 8, 6, 8),
+    "deconv4": ("deconv", 4, 2, 1, 1026, 256, 8, 12, 16),
     "deconv3": ("deconv", 4, 2, 1, 770, 128, 8, 24, 32),
     "deconv2": ("deconv", 4, 2, 1, 386, 64, 8, 48, 64),
     # FlowNet2 batch 4: the full-resolution fusion layers and the SD stem
@@ -72,10 +76,10 @@ def build(name, dtype):
     d.kh = d.kw = k
     d.stride, d.pad, d.act = stride, pad, 1
     d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, layout
-    need = int(lib.fn2_conv2d_workspace_bytes(C.byref(d)))
-    ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device="cuda")
-    if need:
-        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    # room for the maximum split-K factor (16) whatever knobs a variant sets later
+    need = 16 * N * oh * ow * ((cout + 3) // 4 * 4) * 4
+    ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+    d.workspace, d.workspace_bytes = ws.data_ptr(), need
     taps = k * k if kind == "conv" else 4
     flop = 2.0 * N * oh * ow * taps * cin * cout
     return d, flop, (x, wdev, out, ws)
@@ -101,12 +105,22 @@ def main():
         libs.append(l)
     variants = [v for v in a.variants.split(",")]
     for name in a.layers.split(","):
+        for kv in ("FN2_BP64_MIN", "FN2_SPLIT_SLOTS", "FN2_CONV_DBG"):
+            os.environ.pop(kv, None)
         d, flop, keep = build(name, a.dtype)
         times = {v: [] for v in variants}
         s = _hip.stream_ptr()
         for r in range(a.rounds + 2):
             for v in variants:
                 li, dbg = (v[1:].split(":") + ["0"])[:2] if v.startswith("L") else ("0", v)
+                # "dbg/KEY=VAL/KEY=VAL": extra environment knobs of the library for this variant
+                parts = dbg.split("/")
+                dbg = parts[0]
+                for kv in ("FN2_BP64_MIN", "FN2_SPLIT_SLOTS"):
+                    os.environ.pop(kv, None)
+                for kv in parts[1:]:
+                    k_, v_ = kv.split("=")
+                    os.environ[k_] = v_
                 os.environ["FN2_CONV_DBG"] = dbg
                 run = libs[int(li)].fn2_conv2d
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
