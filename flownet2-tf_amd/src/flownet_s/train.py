@@ -1,0 +1,82 @@
+"""python -m src.flownet_s.train --list train.txt --out ./logs [--steps N --batch 8 --checkpoint w.npz --dtype f16x2]
+The reference's src/flownet_s/train.py:8-40 + Net.train (net.py:1002-1400) over the HIP trainer: FlyingChairs-style
+augmentation on the GPU, multiscale EPE loss, Adam on LONG_SCHEDULE, periodic .npz checkpoints under the reference's
+variable names.  Data: a list file of `image_a image_b flow.flo` triples (the reference's TFRecords are built from
+exactly these).  Under torch.distributed.run every rank trains on its own shuffling of the list (seed + rank) and
+the gradients are all-reduced (data parallel)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from ..dataloader import FLYING_CHAIRS_PREPROCESS, load_batches
+from ..training_schedules import LONG_SCHEDULE
+
+
+def unpack_weights(trainer):
+    """fp32 masters in the packed layouts -> {reference variable name: array in the reference layout}."""
+    from ..trainer import _index_hwio
+    out = {}
+    for rec in trainer.eng.layers:
+        name = f"{rec['scope']}/{rec['name']}"
+        flat = rec["master"].cpu().numpy().reshape(-1)
+        if rec["kind"] == "upflow":
+            out[name + "/weights"] = flat.reshape(4, 4, 2, 2).copy()
+        else:
+            out[name + "/weights"] = flat[_index_hwio(rec)].astype(np.float32)
+        if rec.get("b") is not None:
+            out[name + "/biases"] = rec["b"].cpu().numpy().copy()
+    return out
+
+
+def main(flags):
+    import torch
+    from .. import weights as W
+    from ..trainer import FlowNetSTrainer
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("FN2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    wts = W.load_npz(flags.checkpoint) if flags.checkpoint else W.init_weights("FlowNetS", flags.seed)
+    pre = FLYING_CHAIRS_PREPROCESS
+    h, w = (pre["crop_height"], pre["crop_width"]) if flags.augment else (flags.height, flags.width)
+    tr = FlowNetSTrainer(wts, flags.batch, h, w, schedule=LONG_SCHEDULE, dtype=flags.dtype)
+    os.makedirs(flags.out, exist_ok=True)
+    t0 = time.perf_counter()
+    for step, (a, b, f) in enumerate(load_batches(flags.list, flags.batch, pre, flags.augment, seed=flags.seed + rank), 1):
+        loss = tr.train_step(a, b, f)
+        if step % flags.log_every == 0 or step == flags.steps:
+            val = float(loss.item()) + (tr.l2_term() if flags.report_l2 else 0.0)
+            if rank == 0:
+                print("global step %6d | loss %.5f | %.1f pairs/s" % (step, val, world * flags.batch * step /
+                                                                      (time.perf_counter() - t0)), flush=True)
+        if rank == 0 and (step % flags.save_every == 0 or step == flags.steps):
+            W.save_npz(os.path.join(flags.out, "flownet_s-%d.npz" % step), unpack_weights(tr))
+        if step >= flags.steps:
+            break
+    return tr
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--list", required=True, help="text file of `image_a image_b flow.flo` triples")
+    ap.add_argument("--out", required=True, help="directory for the .npz checkpoints")
+    ap.add_argument("--checkpoint", default=None, help=".npz to continue from")
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (the reference's FlyingChairs batch size)")
+    ap.add_argument("--dtype", default="f16x2", choices=["f32", "f16x2"])
+    ap.add_argument("--no-augment", dest="augment", action="store_false")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--log-every", type=int, default=10)
+    ap.add_argument("--save-every", type=int, default=1000)
+    ap.add_argument("--report-l2", action="store_true", help="add the L2 regulariser to the printed loss")
+    FLAGS = ap.parse_args()
+    if not os.path.exists(FLAGS.list):
+        raise ValueError("list path must exist")
+    main(FLAGS)

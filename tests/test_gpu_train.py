@@ -189,3 +189,39 @@ def test_two_rank_data_parallel_equals_full_batch(tmp_path):
     move = np.abs(want_w - w0).max()
     off = np.abs(got["weights"] - want_w) > 0.05 * move
     assert off.mean() < 1e-3, off.mean()
+
+
+@pytest.mark.gpu
+def test_training_cli_pipeline(tmp_path, golden_dir):
+    """List file -> GPU augmentation (FlyingChairs parameters) -> trainer -> .npz checkpoint under the reference's
+    variable names -> reload: the whole training path of src/flownet_s/train.py on the sample pair."""
+    import types
+    from src import flowlib, weights as W
+    from src.dataloader import FLYING_CHAIRS_PREPROCESS, load_batches
+    from src.flownet_s import train as cli
+    s = os.path.join(golden_dir, "samples")
+    lst = tmp_path / "train.txt"
+    row = "%s %s %s\n" % (os.path.join(s, "0img0.ppm"), os.path.join(s, "0img1.ppm"), os.path.join(s, "0flow.flo"))
+    lst.write_text(row * 4)
+    # the loader alone: augmented crops, flow transformed with them
+    a, b, f = next(load_batches(str(lst), 2, FLYING_CHAIRS_PREPROCESS, True, seed=3))
+    assert a.shape == b.shape == (2, 384, 448, 3) and f.shape == (2, 384, 448, 2)
+    assert 0.0 <= float(a.min()) and float(a.max()) <= 1.0 and bool(torch.isfinite(f).all())
+    a0, b0, f0 = next(load_batches(str(lst), 2, FLYING_CHAIRS_PREPROCESS, False, seed=3))
+    assert a0.shape == (2, 384, 512, 3) and np.array_equal(f0[0].cpu().numpy(), flowlib.read_flow(os.path.join(s, "0flow.flo")))
+    flags = types.SimpleNamespace(list=str(lst), out=str(tmp_path / "ckpt"), checkpoint=None, steps=3, batch=2, dtype="f16x2",
+                                  augment=True, height=384, width=512, seed=7, log_every=1, save_every=2, report_l2=True)
+    tr = cli.main(flags)
+    assert tr.step_count == 3
+    saved = W.load_npz(str(tmp_path / "ckpt" / "flownet_s-3.npz"))
+    init = W.init_weights("FlowNetS", 7)
+    assert set(saved) == set(init)
+    moved = max(float(np.abs(saved[k] - init[k]).max()) for k in init if k.endswith("/weights"))
+    assert 1e-5 < moved < 1e-2                               # three Adam steps of lr 1e-4
+    back = cli.unpack_weights(tr)
+    assert all(np.array_equal(back[k], saved[k]) for k in saved)
+    assert os.path.exists(tmp_path / "ckpt" / "flownet_s-2.npz")
+    # resume from the checkpoint
+    flags.checkpoint, flags.steps, flags.augment = str(tmp_path / "ckpt" / "flownet_s-3.npz"), 1, False
+    tr2 = cli.main(flags)
+    assert np.isfinite(float(tr2.loss_dev.item()))
