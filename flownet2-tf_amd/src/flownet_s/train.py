@@ -41,7 +41,7 @@ def main(flags):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("FN2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    wts = W.load_npz(flags.checkpoint) if flags.checkpoint else W.init_weights("FlowNetS", flags.seed)
+    wts = W.load_weights(flags.checkpoint) if flags.checkpoint else W.init_weights("FlowNetS", flags.seed)
     pre = FLYING_CHAIRS_PREPROCESS
     h, w = (pre["crop_height"], pre["crop_width"]) if flags.augment else (flags.height, flags.width)
     tr = FlowNetSTrainer(wts, flags.batch, h, w, schedule=LONG_SCHEDULE, dtype=flags.dtype)

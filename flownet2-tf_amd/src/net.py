@@ -49,10 +49,11 @@ class Net(object):
 
     # ---- weights -----------------------------------------------------------------------------
     def load_weights(self, checkpoint=None, seed=1234):
-        """``checkpoint``: an .npz keyed by the reference's variable names (weights.load_npz).
+        """``checkpoint``: an .npz keyed by the reference's variable names (weights.load_npz) or the .npy dict of the
+        reference's Caffe converter (weights.load_npy).
         A TF checkpoint prefix that does not exist here -> seeded synthetic weights + warning."""
-        if checkpoint is not None and os.path.exists(checkpoint) and checkpoint.endswith(".npz"):
-            self.weights = W.load_npz(checkpoint)
+        if checkpoint is not None and os.path.exists(checkpoint) and checkpoint.endswith((".npz", ".npy")):
+            self.weights = W.load_weights(checkpoint)
         else:
             if checkpoint is not None:
                 sys.stderr.write("WARNING: checkpoint %r not found or not .npz; using seeded synthetic "

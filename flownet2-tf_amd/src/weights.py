@@ -52,6 +52,22 @@ def load_npz(path):
         return {k.replace("__", "/"): z[k] for k in z.files}
 
 
+def load_npy(path):
+    """The `.npy` the reference's Caffe converter writes (scripts/caffe/convert_caffe_weights_to_npy.py:489-496):
+    np.save of a dict {<tf variable>/weights (HWIO; transposed convs HW-O-I), <tf variable>/biases}.  Entries the
+    graphs never read (Caffe's deconvolution biases: biases_initializer=None at flownet_s.py:53) are kept and
+    ignored by the engine."""
+    obj = np.load(path, allow_pickle=True)
+    if obj.dtype != object or obj.shape != ():
+        raise ValueError("%s does not hold a pickled {name: array} dict" % path)
+    return {str(k): np.asarray(v, np.float32) for k, v in obj.item().items()}
+
+
+def load_weights(path):
+    """.npz (this build's checkpoints) or .npy (the reference converter's output)."""
+    return load_npy(path) if str(path).endswith(".npy") else load_npz(path)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 

@@ -226,3 +226,23 @@ def test_interp_weights_and_class_surface():
     assert a.shape == (1, 448, 1024, 3) and m.shape == (1, 448, 1024, 1) and sf.shape == (1, 448, 1024, 2)
     assert info == (1, 436, 1024, 3) and m.max() == 1.0 and a.max() == pytest.approx(200 / 255.0)
     assert sf[0, 440].max() == 0.0
+
+
+def test_caffe_converter_npy_is_ingested(tmp_path):
+    """scripts/caffe/convert_caffe_weights_to_npy.py:489-496 writes np.save(dict): same names and layouts."""
+    from src import weights as W
+    from src.net import Net
+    w = W.init_weights("FlowNetS", 4)
+    extra = dict(w)
+    extra["FlowNetS/deconv5/biases"] = np.zeros(512, np.float32)      # Caffe has them, the TF graph does not read them
+    np.save(tmp_path / "flownet_s.npy", extra)
+    back = W.load_weights(str(tmp_path / "flownet_s.npy"))
+    assert set(back) == set(extra) and all(np.array_equal(back[k], extra[k]) for k in extra)
+
+    class S(Net):
+        model_name = "FlowNetS"
+    n = S()
+    assert set(n.load_weights(str(tmp_path / "flownet_s.npy"))) == set(extra)
+    np.save(tmp_path / "bad.npy", np.zeros(3))
+    with pytest.raises(ValueError):
+        W.load_npy(str(tmp_path / "bad.npy"))
