@@ -1,7 +1,7 @@
 """Debug helper (GPU): Adam steps of the trainer vs the oracle, per layer statistics."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "flownet2-tf_amd"), os.path.join(ROOT, "tests")]
 from oracle import train as reft
 from src import weights as W

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "flownet2-tf_amd")]
 from src import _hip, weights as W  # noqa: E402
 from src.trainer import FlowNetSTrainer, LOSS_WEIGHTS  # noqa: E402

@@ -1,7 +1,7 @@
 """Robustness sweep (GPU): every model at odd batches / sizes runs and stays finite; FlowNetS also against the oracle."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "flownet2-tf_amd")]
 from src import weights as W
 from src.engine import Engine
