@@ -254,3 +254,21 @@ def test_sintel_shape_through_adapt_x():
     assert got.shape == (436, 1024, 2)
     d = got.astype(np.float64) - want
     assert float(np.sqrt((d * d).sum(-1)).mean()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_sample_pair_against_the_committed_fixture(golden_dir, dtype):
+    """The engine on the reference's sample pair against tests/golden/flownets_sample0_golden.npz (no oracle run)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_flownets as gen
+    from src import weights as W
+    from src.engine import Engine
+    g = np.load(os.path.join(golden_dir, "flownets_sample0_golden.npz"))
+    a, b = gen.inputs()
+    out = Engine("FlowNetS", W.init_weights("FlowNetS", 1234), 1, 384, 512, dtype)(a, b)
+    pf6 = out["predict_flow6"].float().cpu().numpy()
+    flow = out["flow"].float().cpu().numpy()
+    assert np.sqrt(((pf6 - g["predict_flow6"]) ** 2).sum(-1)).mean() < 1e-3
+    assert np.sqrt(((flow[0, g["probe_y"], g["probe_x"]] - g["flow_probes"]) ** 2).sum(-1)).mean() < 1e-3

@@ -54,3 +54,20 @@ def test_pad_antipad_leaky_channelnorm():
     np.testing.assert_array_equal(nn.antipad(nn.pad(x, 2), 2), x)
     np.testing.assert_allclose(nn.leaky_relu(x), np.maximum(x, 0.1 * x), rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(nn.channel_norm(x)[..., 0], np.linalg.norm(x, axis=3), rtol=1e-12)
+
+
+def test_config1_flownet_s_on_the_sample_pair_matches_its_fixture(golden_dir):
+    """BASELINE config 1: FlowNetS forward on data/samples/0img0.ppm + 0img1.ppm at 512x384 through the NumPy
+    oracle (seeded weights).  Regression pin of the oracle (tests/golden/make_golden_flownets.py)."""
+    import os
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_flownets as gen
+    from oracle import models as refm
+    from src import weights as W
+    g = np.load(os.path.join(golden_dir, "flownets_sample0_golden.npz"))
+    a, b = gen.inputs()
+    assert a.shape == (1, 384, 512, 3)
+    out = refm.flownet_s(W.init_weights("FlowNetS", 1234), {"input_a": a, "input_b": b})
+    np.testing.assert_allclose(out["predict_flow6"], g["predict_flow6"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(out["flow"][0, g["probe_y"], g["probe_x"]], g["flow_probes"], rtol=1e-9, atol=1e-12)
