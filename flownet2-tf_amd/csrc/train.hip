@@ -248,6 +248,26 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, float*
   }
 }
 
+// All parameter tensors in one launch: blockIdx.y = tensor, blocks of a row stride its elements.  tab[t] =
+// {w, m, v, g} pointers, n[t] elements, l2[t] regulariser (0 for biases / transposed convs).
+struct AdamTensor { float* w; float* m; float* v; const float* g; };
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTensor* __restrict__ tab, const long* __restrict__ n,
+                                                         const float* __restrict__ l2, float lr_t, float b1, float b2,
+                                                         float eps, float gscale) {
+  const AdamTensor t = tab[blockIdx.y];
+  const long cnt = n[blockIdx.y];
+  const float reg = l2[blockIdx.y];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
+    const float wi = t.w[i];
+    const float gi = t.g[i] * gscale + reg * wi;
+    const float mi = b1 * t.m[i] + (1.f - b1) * gi;
+    const float vi = b2 * t.v[i] + (1.f - b2) * gi * gi;
+    t.m[i] = mi;
+    t.v[i] = vi;
+    t.w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
 // upsample_flowXtoY backward (forward: conv-transpose 2->2, k4 s2 crop 1, upsample_flow_kernel in conv.hip):
 //   dpf[n,y,x,i] (+)= sum_{ky,kx,o} g[n,2y+ky-1,2x+kx-1,o] * w[ky,kx,o,i];  dw[ky,kx,o,i] += sum g * pf
 template <typename T>
@@ -855,6 +875,16 @@ int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float
   return FN2_OK;
 }
 
+int fn2_adam_step_multi(const void* table, const int64_t* counts, const float* l2, int n_tensors, float lr, float beta1,
+                        float beta2, float eps, int step, float grad_scale, void* stream) {
+  FN2_REQUIRE(table && counts && l2 && n_tensors >= 1 && n_tensors <= 65535 && step >= 1, "adam_step_multi: bad arguments");
+  const float lr_t = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(128, n_tensors), dim3(256), 0, (hipStream_t)stream,
+                     (const AdamTensor*)table, (const long*)counts, l2, lr_t, beta1, beta2, eps, grad_scale);
+  FN2_CHECK_LAUNCH("adam_multi");
+  return FN2_OK;
+}
+
 int fn2_upsample_flow_bwd(const fn2_tensor* g, const float* pf, const float* w, float* dpf, float* dw, int accumulate,
                           void* stream) {
   FN2_REQUIRE(g && g->data && pf && w && dpf && dw, "upsample_flow_bwd: null pointer");
@@ -876,8 +906,14 @@ int fn2_head_bwd_filter(const fn2_tensor* x, const float* g, float* dw, int cin_
   FN2_REQUIRE((x->dtype == FN2_F32 || x->dtype == FN2_F16X2) && cin_pad >= x->c && kpad >= 9 * cin_pad, "head_bwd_filter: bad layout");
   FN2_REQUIRE(x->cs % 4 == 0 && x->c0 % 4 == 0 && (x->c + 3) / 4 * 4 <= x->cs - x->c0, "head_bwd_filter: x view must be 16-byte aligned and padded to 4 channels");
   const long npix = (long)x->n * x->h * x->w;
+  // pixel ranges: ~512 pixels per block on large maps, but at least ~256 blocks in total on the small ones
+  // (the 6x8 head had 16 blocks walking 384 pixels each: 45 us for a 1.5 MB tensor)
+  const int cblocks = (x->c + 63) / 64;
   int splits = (int)((npix + 511) / 512);
+  const int want = (256 + cblocks - 1) / cblocks;
+  if (splits < want) splits = (int)((npix + 31) / 32 < want ? (npix + 31) / 32 : want);
   if (splits > 512) splits = 512;
+  if (splits < 1) splits = 1;
   if (x->dtype == FN2_F16X2)
     hipLaunchKernelGGL(head_bwd_filter_kernel<x2_t>, dim3((x->c + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream,
                        (const x2_t*)x->data, x->cs, x->c0, x->c, g, dw, cin_pad, kpad, x->n, x->h, x->w);

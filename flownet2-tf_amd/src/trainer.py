@@ -383,10 +383,14 @@ class FlowNetSTrainer:
         b1, b2 = self.schedule["momentum"], self.schedule["momentum2"]
         l2 = self.schedule["l2_regularization"]
         s = _hip.stream_ptr()
-        for p in self.params:
-            _hip.check(self.lib.fn2_adam_step(_hip.ptr(p["w"]), _hip.ptr(p["m"]), _hip.ptr(p["v"]), _hip.ptr(p["g"]),
-                                              p["n"], lr, b1, b2, self.eps, self.step_count,
-                                              l2 if p["reg"] else 0.0, 1.0 / (world * self.loss_scale), s))
+        if getattr(self, "_adam_table", None) is None:  # one launch for all parameter tensors
+            ptrs = [[p["w"].data_ptr(), p["m"].data_ptr(), p["v"].data_ptr(), p["g"].data_ptr()] for p in self.params]
+            self._adam_table = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
+            self._adam_counts = torch.tensor([p["n"] for p in self.params], dtype=torch.int64, device=self.dev)
+            self._adam_l2 = torch.tensor([l2 if p["reg"] else 0.0 for p in self.params], dtype=torch.float32, device=self.dev)
+        _hip.check(self.lib.fn2_adam_step_multi(_hip.ptr(self._adam_table), _hip.ptr(self._adam_counts),
+                                                _hip.ptr(self._adam_l2), len(self.params), lr, b1, b2, self.eps,
+                                                self.step_count, 1.0 / (world * self.loss_scale), s))
         self.refresh_backward_weights()
 
     def train_step(self, input_a, input_b, gt_flow):

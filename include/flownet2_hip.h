@@ -237,6 +237,11 @@ int fn2_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, 
 /* tf.train.AdamOptimizer update of n parameters with g' = grad_scale*g + l2*w (slim l2_regularizer). */
 int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float l2, float grad_scale, void* stream);
+/* The same update for n_tensors parameter tensors in ONE launch.  table: device array of {float* w, float* m,
+ * float* v, const float* g} (4 pointers per tensor); counts / l2: device arrays of element counts (int64) and L2
+ * coefficients (0 where the reference does not regularise). */
+int fn2_adam_step_multi(const void* table, const int64_t* counts, const float* l2, int n_tensors, float lr, float beta1,
+                        float beta2, float eps, int step, float grad_scale, void* stream);
 /* upsample_flowXtoY backward: g = gradient view [n,2h,2w,2] of its output slice, pf its fp32 input [n,h,w,2],
  * w [4][4][2][2]; dpf (+)= input gradient, dw += filter gradient. */
 int fn2_upsample_flow_bwd(const fn2_tensor* g, const float* pf, const float* w, float* dpf, float* dw,
