@@ -189,7 +189,8 @@ int fn2_pack_pair(const float* a, const float* b, const fn2_tensor* out, int pad
 /* image fp32 [n_img,h,w,3] -> batch rows [n0, n0+n_img) of the out view, 3 (pad 8) channels
  * (the siamese towers of FlowNetC run as one 2N batch, flownet_c.py:30-37) */
 int fn2_pack_image(const float* img, int n_img, const fn2_tensor* out, int n0, int pad, void* stream);
-/* Space-to-depth variant for a stride-2 stem on a 3-channel image: out[n, sy, sx, (py*2+px)*4 + c] =
+/* Space-to-depth variant for a stride-2 stem on a 3-channel image (FlowNetC's pad(.., 3) + conv1 7x7 stride 2 on
+ * each image, flownet_c.py:30-37): out[n, sy, sx, (py*2+px)*4 + c] =
  * zero-padded img[2sy+py-pad, 2sx+px-pad, c]; out is the WHOLE [n_total, (h+2pad)/2, (w+2pad)/2, 16] buffer.  The
  * k x k stride-2 convolution becomes a ceil(k/2)^2 stride-1 kind-2 convolution with the weights re-indexed
  * w'[ky', kx', (py*2+px)*4+c] = w[2ky'+py, 2kx'+px, c] (zero past k). */
@@ -237,7 +238,8 @@ int fn2_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, 
 /* tf.train.AdamOptimizer update of n parameters with g' = grad_scale*g + l2*w (slim l2_regularizer). */
 int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float l2, float grad_scale, void* stream);
-/* The same update for n_tensors parameter tensors in ONE launch.  table: device array of {float* w, float* m,
+/* The same update (tf.train.AdamOptimizer.apply_gradients, net.py:1290-1295) for n_tensors parameter tensors in
+ * ONE launch.  table: device array of {float* w, float* m,
  * float* v, const float* g} (4 pointers per tensor); counts / l2: device arrays of element counts (int64) and L2
  * coefficients (0 where the reference does not regularise). */
 int fn2_adam_step_multi(const void* table, const int64_t* counts, const float* l2, int n_tensors, float lr, float beta1,
