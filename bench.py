@@ -49,8 +49,9 @@ def stored_traffic(model, batch, dtype, kernel):
     if not os.path.exists(path):
         return None
     table = json.load(open(path))
+    stem = kernel.rstrip(">")  # the bench names an instantiation without its defaulted trailing template arguments
     for k, v in table.items():
-        if kernel in k:
+        if stem in k:
             return round(v["hbm_bytes_per_launch"])
     return None
 
