@@ -49,6 +49,7 @@ _tp = C.POINTER(Fn2Tensor)
 PROTOTYPES = {
     "fn2_last_error": (C.c_char_p, []),
     "fn2_version": (_i, []),
+    "fn2_crc32c": (C.c_uint32, [_p, C.c_int64, C.c_uint32]),
     "fn2_device_info": (_i, [C.c_char_p, _i, _ip]),
     "fn2_correlation_out_shape": (_i, [_i] * 7 + [_ip] * 3),
     "fn2_correlation_f32": (_i, [_p, _p, _p] + [_i] * 9 + [_p]),

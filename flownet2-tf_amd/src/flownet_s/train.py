@@ -1,4 +1,5 @@
-"""python -m src.flownet_s.train --list train.txt --out ./logs [--steps N --batch 8 --checkpoint w.npz --dtype f16x2]
+"""python -m src.flownet_s.train --list train.txt --out ./logs [--steps N --batch 8 --checkpoint w.npz --dtype f16x2
+                                 --ckpt-format npz|tf]
 The reference's src/flownet_s/train.py:8-40 + Net.train (net.py:1002-1400) over the HIP trainer: FlyingChairs-style
 augmentation on the GPU, multiscale EPE loss, Adam on LONG_SCHEDULE, periodic .npz checkpoints under the reference's
 variable names.  Data: a list file of `image_a image_b flow.flo` triples (the reference's TFRecords are built from
@@ -31,6 +32,23 @@ def unpack_weights(trainer):
     return out
 
 
+def save_checkpoint(out_dir, step, weights, fmt="npz"):
+    """npz: flownet_s-<step>.npz.  tf: model.ckpt-<step>.{index,data-00000-of-00001} + the `checkpoint` state file,
+    the files the reference's slim Saver leaves in its log dir (net.py:1386-1392) and that both this package and
+    tf.train.Saver.restore read (variables under the reference names + global_step)."""
+    from .. import weights as W
+    if fmt == "tf":
+        from .. import tf_checkpoint
+        name = "model.ckpt-%d" % step
+        tf_checkpoint.save_tf_checkpoint(os.path.join(out_dir, name), dict(weights, global_step=np.int64(step)))
+        with open(os.path.join(out_dir, "checkpoint"), "w") as f:
+            f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
+        return os.path.join(out_dir, name)
+    path = os.path.join(out_dir, "flownet_s-%d.npz" % step)
+    W.save_npz(path, weights)
+    return path
+
+
 def main(flags):
     import torch
     from .. import weights as W
@@ -55,7 +73,7 @@ def main(flags):
                 print("global step %6d | loss %.5f | %.1f pairs/s" % (step, val, world * flags.batch * step /
                                                                       (time.perf_counter() - t0)), flush=True)
         if rank == 0 and (step % flags.save_every == 0 or step == flags.steps):
-            W.save_npz(os.path.join(flags.out, "flownet_s-%d.npz" % step), unpack_weights(tr))
+            save_checkpoint(flags.out, step, unpack_weights(tr), flags.ckpt_format)
         if step >= flags.steps:
             break
     return tr
@@ -65,7 +83,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--list", required=True, help="text file of `image_a image_b flow.flo` triples")
     ap.add_argument("--out", required=True, help="directory for the .npz checkpoints")
-    ap.add_argument("--checkpoint", default=None, help=".npz to continue from")
+    ap.add_argument("--checkpoint", default=None, help=".npz / .npy / TensorFlow checkpoint prefix to continue from")
+    ap.add_argument("--ckpt-format", default="npz", choices=["npz", "tf"],
+                    help="tf: model.ckpt-<step> TensorFlow V2 bundles (readable by the reference's Saver.restore)")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (the reference's FlyingChairs batch size)")
     ap.add_argument("--dtype", default="f16x2", choices=["f32", "f16x2"])

@@ -49,14 +49,15 @@ class Net(object):
 
     # ---- weights -----------------------------------------------------------------------------
     def load_weights(self, checkpoint=None, seed=1234):
-        """``checkpoint``: an .npz keyed by the reference's variable names (weights.load_npz) or the .npy dict of the
-        reference's Caffe converter (weights.load_npy).
-        A TF checkpoint prefix that does not exist here -> seeded synthetic weights + warning."""
-        if checkpoint is not None and os.path.exists(checkpoint) and checkpoint.endswith((".npz", ".npy")):
+        """``checkpoint``: a TensorFlow V2 checkpoint prefix as the reference restores it (``.../flownet-S.ckpt-0``
+        with ``.index`` + ``.data-*``; src/tf_checkpoint.py reads the bundle without TensorFlow), an .npz keyed by
+        the reference's variable names (weights.load_npz) or the .npy dict of the reference's Caffe converter
+        (weights.load_npy).  A checkpoint that does not exist here -> seeded synthetic weights + warning."""
+        if checkpoint is not None and W.checkpoint_exists(checkpoint):
             self.weights = W.load_weights(checkpoint)
         else:
             if checkpoint is not None:
-                sys.stderr.write("WARNING: checkpoint %r not found or not .npz; using seeded synthetic "
+                sys.stderr.write("WARNING: checkpoint %r not found (TF bundle prefix, .npz or .npy); using seeded synthetic "
                                  "weights (seed %d) -- flows are NOT meaningful predictions\n" % (checkpoint, seed))
             self.weights = W.init_weights(self.model_name, seed)
         self._engines = {}

@@ -6,6 +6,8 @@ use seeded variance-scaling weights; real weights converted by the reference's
 scripts/caffe/convert_caffe_weights_to_npy.py (HWIO / HW-O-I, names
 ``<scope>/<layer>/weights|biases``) load through ``load_npz`` unchanged.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -64,8 +66,24 @@ def load_npy(path):
 
 
 def load_weights(path):
-    """.npz (this build's checkpoints) or .npy (the reference converter's output)."""
-    return load_npy(path) if str(path).endswith(".npy") else load_npz(path)
+    """.npz (this build's checkpoints), .npy (the reference converter's output) or a TensorFlow V2 checkpoint
+    prefix (``flownet-S.ckpt-0`` with its ``.index`` / ``.data-*`` files: what the reference's Saver restores,
+    src/net.py:566-569)."""
+    from . import tf_checkpoint
+    path = str(path)
+    for suffix in (".index", ".data-00000-of-00001", ".meta"):  # any file of the bundle names the bundle
+        if path.endswith(suffix) and tf_checkpoint.is_tf_checkpoint(path[:-len(suffix)]):
+            path = path[:-len(suffix)]
+    if tf_checkpoint.is_tf_checkpoint(path):
+        return tf_checkpoint.load_tf_checkpoint(path)
+    return load_npy(path) if path.endswith(".npy") else load_npz(path)
+
+
+def checkpoint_exists(path):
+    from . import tf_checkpoint
+    path = str(path)
+    return tf_checkpoint.is_tf_checkpoint(path) or (os.path.exists(path) and path.endswith(
+        (".npz", ".npy", ".index", ".data-00000-of-00001")))
 
 
 def _round_up(x, m):

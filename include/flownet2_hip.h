@@ -78,6 +78,10 @@ typedef struct {
 
 const char* fn2_last_error(void);
 int fn2_version(void);
+/* CRC-32C (Castagnoli, reflected 0x82F63B78) of n bytes of HOST memory, continuing from `crc` (0 to start): the
+ * checksum of the TensorFlow checkpoint bundle and TFRecord containers the reference reads and writes through
+ * tf.train.Saver (src/net.py:566-569, :1386-1392) and tf.data.TFRecordDataset (src/dataloader.py).  Host-only. */
+uint32_t fn2_crc32c(const void* data, int64_t n, uint32_t crc);
 /* Fills name (<= cap bytes) with the gcnArchName of the current device, *cus with its CU count. */
 int fn2_device_info(char* name, int cap, int* cus);
 

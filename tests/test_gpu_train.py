@@ -210,7 +210,8 @@ def test_training_cli_pipeline(tmp_path, golden_dir):
     a0, b0, f0 = next(load_batches(str(lst), 2, FLYING_CHAIRS_PREPROCESS, False, seed=3))
     assert a0.shape == (2, 384, 512, 3) and np.array_equal(f0[0].cpu().numpy(), flowlib.read_flow(os.path.join(s, "0flow.flo")))
     flags = types.SimpleNamespace(list=str(lst), out=str(tmp_path / "ckpt"), checkpoint=None, steps=3, batch=2, dtype="f16x2",
-                                  augment=True, height=384, width=512, seed=7, log_every=1, save_every=2, report_l2=True)
+                                  augment=True, height=384, width=512, seed=7, log_every=1, save_every=2, report_l2=True,
+                                  ckpt_format="npz")
     tr = cli.main(flags)
     assert tr.step_count == 3
     saved = W.load_npz(str(tmp_path / "ckpt" / "flownet_s-3.npz"))
@@ -223,5 +224,10 @@ def test_training_cli_pipeline(tmp_path, golden_dir):
     assert os.path.exists(tmp_path / "ckpt" / "flownet_s-2.npz")
     # resume from the checkpoint
     flags.checkpoint, flags.steps, flags.augment = str(tmp_path / "ckpt" / "flownet_s-3.npz"), 1, False
+    flags.ckpt_format = "tf"  # ... and leave a TensorFlow bundle (model.ckpt-1 + `checkpoint`) like the slim Saver
     tr2 = cli.main(flags)
     assert np.isfinite(float(tr2.loss_dev.item()))
+    bundle = W.load_weights(str(tmp_path / "ckpt" / "model.ckpt-1"))
+    back2 = cli.unpack_weights(tr2)
+    assert set(bundle) == set(back2) and all(np.array_equal(bundle[k], back2[k]) for k in back2)
+    assert 'model.ckpt-1' in open(tmp_path / "ckpt" / "checkpoint").read()
