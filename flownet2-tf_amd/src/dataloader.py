@@ -1,7 +1,7 @@
 """Training input pipeline of the reference (src/dataloader.py:383-560 `load_batch`, src/dataset_configs.py)
-re-expressed for list files: the reference reads TFRecords it cannot ship; here a text file lists
-`image_a image_b flow.flo` per line (the same triples the TFRecords were built from), samples are batched on the
-host, and the augmentation runs on the GPU through the preprocessing plugin's op surface (src/preprocessing.py):
+over two sample sources: the reference's ZLIB TFRecord files (src/tfrecord.py reads them without TensorFlow) or a
+text file listing `image_a image_b flow.flo` per line (the triples the TFRecords were built from); samples are
+batched on the host, and the augmentation runs on the GPU through the preprocessing plugin's op surface (src/preprocessing.py):
 DataAugmentation on both images (image b inherits image a's transform), FlowAugmentation on the ground truth.
 
 PREPROCESS values are the reference's FlyingChairs configuration (dataset_configs.py:60-157) as data.
@@ -64,24 +64,60 @@ def read_list(path):
     return rows
 
 
-def load_batches(list_path, batch_size, preprocess=FLYING_CHAIRS_PREPROCESS, data_augmentation=True, seed=0,
-                 global_step=0, epochs=None):
-    """Generator of (image_a, image_b, flow) device tensors [B,h,w,3|3|2]; images in [0,1].  With
-    data_augmentation the crop is (crop_height, crop_width) and the flow is transformed with the two augmentation
-    matrices (dataloader.py:480-540); without it the samples pass through unchanged."""
+def _list_epoch(rows, rng):
+    """One epoch of (image_a, image_b, flow) host arrays from a list file, in a fresh random order."""
     from .net import imread
-    rows = read_list(list_path)
+    for j in rng.permutation(len(rows)):
+        r = rows[j]
+        yield imread(r[0]).astype(np.float32) / 255.0, imread(r[1]).astype(np.float32) / 255.0, read_flow(r[2])
+
+
+def _tfrecord_epoch(path, rng, image_size, scale, shuffle_buffer):
+    """One epoch over a TFRecord file of the reference's samples (src/tfrecord.py), shuffled through a bounded
+    buffer like the reference's slim DatasetDataProvider queue (dataloader.py:444-451: common_queue_capacity)."""
+    from . import tfrecord
+    buf = []
+    div = 255.0 if scale else 1.0  # records hold images already in [0,1] unless PREPROCESS['scale'] (dataloader.py:466)
+    for smp in tfrecord.read_samples(path, image_size[0], image_size[1]):
+        item = (smp["image_a"] / div, smp["image_b"] / div, smp["flow"])
+        if len(buf) < shuffle_buffer:
+            buf.append(item)
+            continue
+        k = int(rng.integers(len(buf)))
+        out, buf[k] = buf[k], item
+        yield out
+    for k in rng.permutation(len(buf)):
+        yield buf[k]
+
+
+def is_tfrecord(path):
+    return str(path).endswith((".tfrecords", ".tfrecord"))
+
+
+def load_batches(list_path, batch_size, preprocess=FLYING_CHAIRS_PREPROCESS, data_augmentation=True, seed=0,
+                 global_step=0, epochs=None, image_size=(384, 512), shuffle_buffer=256):
+    """Generator of (image_a, image_b, flow) device tensors [B,h,w,3|3|2]; images in [0,1].  ``list_path`` is a
+    text file of `image_a image_b flow.flo` triples or a ``.tfrecords`` file as the reference's converter writes it
+    (``image_size`` = the dataset's PADDED_IMAGE_HEIGHT/WIDTH, dataset_configs.py:42-43).  With data_augmentation
+    the crop is (crop_height, crop_width) and the flow is transformed with the two augmentation matrices
+    (dataloader.py:480-540); without it the samples pass through unchanged."""
     rng = np.random.default_rng(seed)
+    rows = None if is_tfrecord(list_path) else read_list(list_path)
     a_cfg, b_cfg = config_to_arrays(preprocess["image_a"]), config_to_arrays(preprocess["image_b"])
     crop = (preprocess["crop_height"], preprocess["crop_width"])
     epoch, step = 0, int(global_step)
     while epochs is None or epoch < epochs:
-        order = rng.permutation(len(rows))
-        for i in range(0, len(order) - batch_size + 1, batch_size):
-            pick = [rows[j] for j in order[i:i + batch_size]]
-            a = np.stack([imread(r[0]) for r in pick]).astype(np.float32) / 255.0
-            b = np.stack([imread(r[1]) for r in pick]).astype(np.float32) / 255.0
-            f = np.stack([read_flow(r[2]) for r in pick])
+        source = _list_epoch(rows, rng) if rows is not None else _tfrecord_epoch(
+            list_path, rng, image_size, bool(preprocess.get("scale", False)), shuffle_buffer)
+        pick = []
+        produced = False
+        for smp in source:
+            pick.append(smp)
+            if len(pick) < batch_size:
+                continue
+            a, b, f = (np.stack([p[i] for p in pick]).astype(np.float32) for i in range(3))
+            pick = []
+            produced = True
             if not data_augmentation:
                 dev = lambda x: torch.from_numpy(x).to(P._hip.require_device())
                 yield dev(a), dev(b), dev(f)
@@ -99,4 +135,6 @@ def load_batches(list_path, batch_size, preprocess=FLYING_CHAIRS_PREPROCESS, dat
                     ob = (ob + sigma * torch.randn(ob.shape, generator=g, device=ob.device)).clamp_(0.0, 1.0)
                 yield oa, ob, P.flow_augmentation(f, ta, itb, crop)
             step += 1
+        if not produced:
+            raise ValueError("%s holds fewer than one batch (%d) of samples" % (list_path, batch_size))
         epoch += 1

@@ -81,7 +81,8 @@ def main(flags):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--list", required=True, help="text file of `image_a image_b flow.flo` triples")
+    ap.add_argument("--list", required=True, help="text file of `image_a image_b flow.flo` triples, or a .tfrecords file of the "
+                                                  "reference's converter (python -m src.tfrecord builds one)")
     ap.add_argument("--out", required=True, help="directory for the .npz checkpoints")
     ap.add_argument("--checkpoint", default=None, help=".npz / .npy / TensorFlow checkpoint prefix to continue from")
     ap.add_argument("--ckpt-format", default="npz", choices=["npz", "tf"],

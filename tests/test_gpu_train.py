@@ -224,6 +224,15 @@ def test_training_cli_pipeline(tmp_path, golden_dir):
     assert os.path.exists(tmp_path / "ckpt" / "flownet_s-2.npz")
     # resume from the checkpoint
     flags.checkpoint, flags.steps, flags.augment = str(tmp_path / "ckpt" / "flownet_s-3.npz"), 1, False
+    # the same samples as a ZLIB TFRecord file (the reference's training input format)
+    from src import tfrecord
+    rec = str(tmp_path / "fc_train_all.tfrecords")
+    assert tfrecord.convert_list(str(lst), rec) == 4
+    ar, br, fr = next(load_batches(rec, 2, FLYING_CHAIRS_PREPROCESS, False, seed=3))
+    assert ar.shape == (2, 384, 512, 3) and torch.equal(ar[0], a0[0]) and torch.equal(fr[0], f0[0])
+    aa, _, fa = next(load_batches(rec, 2, FLYING_CHAIRS_PREPROCESS, True, seed=3))
+    assert aa.shape == (2, 384, 448, 3) and fa.shape == (2, 384, 448, 2)
+    flags.list = rec
     flags.ckpt_format = "tf"  # ... and leave a TensorFlow bundle (model.ckpt-1 + `checkpoint`) like the slim Saver
     tr2 = cli.main(flags)
     assert np.isfinite(float(tr2.loss_dev.item()))
