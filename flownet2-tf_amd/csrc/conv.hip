@@ -741,6 +741,16 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   // experiment (bit 64): weight-streaming 128-cout layers (the ones left on 128 x 128 + split-K) on 128 x 64 tiles
   // with the 3-slot ring
   if ((a.dbg & 64) && d->wgt_layout == 1 && tile == 128 && !a.bp64) a.bp64 = 2;
+  // 128 x 64 layers whose grid is at most two blocks per CU and takes no split-K (384..512 blocks: conv4_1 / deconv3
+  // at batch 8, conv3 / conv3_1 at batch 4): the 3-slot ring's 72 KB of LDS costs them no resident block and keeps
+  // two stages of DMA in flight instead of one (+4..7 %; with a third resident block to lose it is 5-12 % slower).
+  // FN2_RING_MAX = largest such grid (0 = never); FN2_CONV_DBG bit 256 = ring on every 128 x 64 layer (A/B).
+  // (the same rule on the 64- and 32-cout tiles measured neutral: not instantiated)
+  if (d->wgt_layout == 1 && tile == 128 && a.bp64 == 1) {
+    static const int ring_max = [] { const char* e = getenv("FN2_RING_MAX"); return e ? atoi(e) : 512; }();
+    const long blocks = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * phases;
+    if ((a.dbg & 256) || (blocks >= 384 && blocks <= ring_max)) a.bp64 = 2;
+  }
   *tile_out = tile;
   *phases_out = phases;
   return FN2_OK;

@@ -304,9 +304,10 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     // stage s-1: its ds_reads were consumed by MFMAs before the barrier), refill that slot two stages ahead.
     // __syncthreads() would not do: its fence drains vmcnt to 0, i.e. waits for the look-ahead stage as well.
     constexpr int ND = NWI + NPI;
-    static_assert(ND == 6 || ND == 8, "vmcnt literal below");
+    static_assert(ND == 5 || ND == 6 || ND == 8, "vmcnt literal below");
     auto ring_sync = [] {
-      if constexpr (ND == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      if constexpr (ND == 5) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+      else if constexpr (ND == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     };
     issue_stage(lds0);
