@@ -421,9 +421,11 @@ static int launch_conv(const ConvArgs& a, int tile, int phases_, hipStream_t s) 
 // 18 outputs, t[pix][tap*2 + co] = sum_ci x[pix][ci] * w[tap][ci][co] (the activations are read ONCE, on the
 // matrix cores, instead of nine times by the dot-product kernel); this kernel adds the nine shifted partials:
 //   out[n,y,x,co] = bias[co] + sum_{ky,kx} t[n, y+ky-1, x+kx-1][(ky*3+kx)*2 + co]    (zero outside the image)
-__global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __restrict__ t, int t_cs,
-                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                               int N, int H, int W) {
+// Small heads (the 6x8 .. 96x128 levels: a handful of blocks, latency-bound): one thread per output pixel, nine
+// 8-byte loads each.
+__global__ void __launch_bounds__(256) flow_head_gather_small_kernel(const float* __restrict__ t, int t_cs,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ out, int N, int H, int W) {
   const long total = (long)N * H * W;
   const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -442,6 +444,53 @@ __global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __re
       }
     }
     *reinterpret_cast<float2*>(out + 2 * i) = make_float2(a0, a1);
+  }
+}
+
+// One block = a GT_Y x GT_X tile of output pixels of one image: the (GT_Y+2) x (GT_X+2) halo of partials goes
+// through LDS with coalesced 72-byte runs per pixel, every lane then sums its nine taps from LDS (lane stride 72 B:
+// conflict-free for ds_read_b64).  The first form (one thread per pixel, nine 8-byte loads at 128-byte lane stride
+// straight from memory) ran at 0.5 TB/s on big heads: 0.122 ms for FlowNet2's full-resolution one, now 0.029 ms.
+constexpr int GT_X = 64, GT_Y = 8;
+__global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __restrict__ t, int t_cs,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int N, int H, int W) {
+  constexpr int HX = GT_X + 2, HY = GT_Y + 2;
+  __shared__ float2 sm[HY * HX * 9];
+  const int tiles_x = (W + GT_X - 1) / GT_X, tiles_y = (H + GT_Y - 1) / GT_Y;
+  const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+  const int tid = threadIdx.x;
+  for (int blk = blockIdx.x; blk < N * tiles_y * tiles_x; blk += gridDim.x) {
+    const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, n = blk / (tiles_x * tiles_y);
+    const int x0 = tx * GT_X - 1, y0 = ty * GT_Y - 1;
+    for (int idx = tid; idx < HY * HX * 9; idx += 256) {
+      const int p = idx / 9, j = idx - p * 9;
+      const int hy = p / HX, hx = p - hy * HX;
+      const int gy = y0 + hy, gx = x0 + hx;
+      float2 v = make_float2(0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const float2*>(t + (((long)n * H + gy) * W + gx) * t_cs + 2 * j);
+      sm[idx] = v;
+    }
+    __syncthreads();
+    const int px = tid & (GT_X - 1);
+#pragma unroll
+    for (int r = 0; r < GT_Y / 4; ++r) {
+      const int py = (tid >> 6) + 4 * r;
+      const int oy = ty * GT_Y + py, ox = tx * GT_X + px;
+      if (oy < H && ox < W) {
+        float a0 = b0, a1 = b1;  // same summation order as the reference order of taps: ky outer, kx inner
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float2 v = sm[((py + ky) * HX + px + kx) * 9 + ky * 3 + kx];
+            a0 += v.x; a1 += v.y;
+          }
+        *reinterpret_cast<float2*>(out + (((long)n * H + oy) * W + ox) * 2) = make_float2(a0, a1);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -856,8 +905,13 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
 int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out, int n, int h, int w, void* stream) {
   FN2_REQUIRE(t && out, "flow_head_gather: null pointer");
   FN2_REQUIRE(t_cs >= 18 && t_cs % 2 == 0 && n >= 1 && h >= 1 && w >= 1, "flow_head_gather: t must hold 18 partials per pixel");
-  hipLaunchKernelGGL(flow_head_gather_kernel, dim3(grid_for((long)n * h * w, 256)), dim3(256), 0, (hipStream_t)stream, t,
-                     t_cs, bias, out, n, h, w);
+  const long tiles = (long)n * ((h + GT_Y - 1) / GT_Y) * ((w + GT_X - 1) / GT_X);
+  if (tiles >= 1024)  // >= 4 tiles per CU: the LDS-tiled form pays (full-resolution heads)
+    hipLaunchKernelGGL(flow_head_gather_kernel, dim3((unsigned)std::min<long>(tiles, 1 << 16)), dim3(256), 0,
+                       (hipStream_t)stream, t, t_cs, bias, out, n, h, w);
+  else
+    hipLaunchKernelGGL(flow_head_gather_small_kernel, dim3(grid_for((long)n * h * w, 256)), dim3(256), 0,
+                       (hipStream_t)stream, t, t_cs, bias, out, n, h, w);
   FN2_CHECK_LAUNCH("flow_head_gather");
   return FN2_OK;
 }

@@ -334,3 +334,27 @@ def test_conv_random_shapes_cover_every_tile_variant(dtype):
         want = refnn.conv2d_transpose(x, w, activation=refnn.leaky_relu)
         got = run_conv(x, w, None, "deconv", 4, 2, 1, True, dtype, cout_off=8)
         np.testing.assert_allclose(got, want, rtol=3e-5, atol=3e-5, err_msg=str((cin, cout, H, Wd)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(3, 384, 512), (90, 50, 70), (2, 6, 8), (1, 96, 128)])
+def test_flow_head_gather_small_and_tiled(N, H, W):
+    """fn2_flow_head_gather: out[n,y,x,co] = bias[co] + sum_taps t[n,y+ky-1,x+kx-1][(ky*3+kx)*2+co] with zeros outside
+    the image (the second half of predict_flowN, flownet_s.py:54-56) -- both launch forms (LDS-tiled from 1024 tiles
+    up, thread-per-pixel below), ragged tile edges included; same tap order, so the two agree bit for bit."""
+    from src import _hip
+    lib = _hip.lib()
+    rng = np.random.default_rng(N * 1000 + H)
+    t = rng.standard_normal((N, H, W, 32)).astype(np.float32)
+    bias = np.array([0.25, -1.5], np.float32)
+    want = np.zeros((N, H, W, 2), np.float32) + bias
+    tp = np.pad(t, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for ky in range(3):          # fp32 accumulation in the kernel's order
+        for kx in range(3):
+            j = (ky * 3 + kx) * 2
+            want = want + tp[:, ky:ky + H, kx:kx + W, j:j + 2]
+    td, bd = torch.from_numpy(t).cuda(), torch.from_numpy(bias).cuda()
+    out = torch.full((N, H, W, 2), float("nan"), dtype=torch.float32, device="cuda")
+    _hip.check(lib.fn2_flow_head_gather(td.data_ptr(), 32, bd.data_ptr(), out.data_ptr(), N, H, W, _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
