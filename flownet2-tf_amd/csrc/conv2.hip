@@ -33,6 +33,18 @@
 #ifndef FN2_X2_ORDER
 #define FN2_X2_ORDER 0
 #endif
+// 1: the FN2_CONV_DBG ablation switches of the main loop (bits 1, 2: skip the pixel / weight DMA; 16: tap-outer K order)
+// are compiled in (tools/build_variant.sh abl "-DFN2_CONV_ABLATE=1" for the experiments of DESIGN.md section 7);
+// 0 (default): compiled out -- no scalar branches between the DMA pieces
+#ifndef FN2_CONV_ABLATE
+#define FN2_CONV_ABLATE 0
+#endif
+// 1 (default): raise the wave priority over the MFMA section of a stage (s_setprio): a wave that has its fragments
+// issues its matrix instructions ahead of co-resident waves still issuing DMA pieces.  Together with the switch above
+// +0.6..1.6 % on the large layers, +4.5 % on conv5_1, neutral on the ring layers (same-process A/B, tools/ab_conv.py)
+#ifndef FN2_SETPRIO
+#define FN2_SETPRIO 1
+#endif
 
 namespace fn2 {
 
@@ -157,7 +169,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   // fetching their input 6-9 times (conv3_1: 449 MB for a 47 MB input).  Only the summation order changes.
   const int spt = p.cin_chunks >> 3;  // 128-byte stages per tap
   const int ntap = p.KH * p.KW;
-  const bool tap_outer = p.dbg & 16;  // A/B switch: the first version's order
+  const bool tap_outer = FN2_CONV_ABLATE && (p.dbg & 16);  // A/B switch: the first version's order
   int sc = tap_outer ? kt0 % spt : kt0 / ntap;  // channel block of stage kt0
   int tap = tap_outer ? kt0 / spt : kt0 - sc * ntap;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -166,14 +178,14 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   auto issue_piece = [&](auto piece_c, uint4* lds) {
     constexpr int i = decltype(piece_c)::value;
     if constexpr (i < NWI) {
-      if (!(p.dbg & 2))
+      if (!(FN2_CONV_ABLATE && (p.dbg & 2)))
         dma16(rsrc_w, &lds[(wave * (BC / 4) + i * 8) * 8], woff[i], ((ky * p.KW + kx) * spt + sc) * 128);
     } else {
       constexpr int j = i - NWI;
       const unsigned tbit = (1u << ky) | (1u << (8 + kx));
       const int toff = ((ky * p.W + kx) * p.in_cs + sc * 8 * CH) * ESZ;
       const unsigned voff = ((vmask[j] & tbit) == tbit && wstage < kt1) ? (unsigned)(roff[j] + toff) : kOobOffset;
-      if (!(p.dbg & 1))
+      if (!(FN2_CONV_ABLATE && (p.dbg & 1)))
         dma16(rsrc_x, &lds[(BC + wave * (BP / 4) + j * 8) * 8], voff, 0);
     }
   };
@@ -209,6 +221,9 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
 
   // one stage of MFMAs on the LDS object `lds`
   auto compute = [&](const uint4* lds) {
+#if FN2_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     const uint4* A = &lds[(wc * TCN * 32 + fr) * 8];
     const uint4* B = &lds[(BC + wp * TPN * 32 + fr) * 8];
     if constexpr (is_x2<T>::value) {
@@ -272,6 +287,9 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
         }
       }
     }
+#if FN2_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // NOTE: nothing conditional may wrap the MFMAs: an `if` around them made hipcc shuttle all 64
