@@ -544,8 +544,9 @@ __global__ void __launch_bounds__(256) pack_image_kernel(const float* __restrict
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % w), y = (int)((i / w) % h), nn = (int)(i / w / h);
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    v[0] = img0[i * 3]; v[1] = img0[i * 3 + 1]; v[2] = img0[i * 3 + 2];
-    if (NIMG == 2) { v[3] = img1[i * 3]; v[4] = img1[i * 3 + 1]; v[5] = img1[i * 3 + 2]; }
+    const rgb3_t p0 = load_rgb(img0 + i * 3);  // one 12-byte load per pixel (fn2_common.h)
+    v[0] = p0.r; v[1] = p0.g; v[2] = p0.b;
+    if (NIMG == 2) { const rgb3_t p1 = load_rgb(img1 + i * 3); v[3] = p1.r; v[4] = p1.g; v[5] = p1.b; }
     OutT* d = out + (((size_t)(n0 + nn) * hp + y + pad) * wp + x + pad) * out_cs + c0;
     if constexpr (is_x2<OutT>::value) {
       uint4* q = reinterpret_cast<uint4*>(d);
@@ -575,7 +576,8 @@ __global__ void __launch_bounds__(256) pack_image_s2d_kernel(const float* __rest
       const int y = 2 * sy + (q >> 1) - pad, x = 2 * sx + (q & 1) - pad;
       const bool ok = y >= 0 && y < h && x >= 0 && x < w;
       const float* p = img + (((long)nn * h + (ok ? y : 0)) * w + (ok ? x : 0)) * 3;
-      v[q * 4 + 0] = ok ? p[0] : 0.f; v[q * 4 + 1] = ok ? p[1] : 0.f; v[q * 4 + 2] = ok ? p[2] : 0.f; v[q * 4 + 3] = 0.f;
+      const rgb3_t px = load_rgb(p);  // one 12-byte load per pixel (fn2_common.h)
+      v[q * 4 + 0] = ok ? px.r : 0.f; v[q * 4 + 1] = ok ? px.g : 0.f; v[q * 4 + 2] = ok ? px.b : 0.f; v[q * 4 + 3] = 0.f;
     }
     OutT* d = out + (((size_t)(n0 + nn) * hs + sy) * ws + sx) * out_cs;
     if constexpr (is_x2<OutT>::value) {
@@ -796,7 +798,8 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   // FN2_RING_MAX = largest such grid (0 = never); FN2_CONV_DBG bit 256 = ring on every 128 x 64 layer (A/B).
   // (the same rule on the 64- and 32-cout tiles measured neutral: not instantiated)
   if (d->wgt_layout == 1 && tile == 128 && a.bp64 == 1) {
-    static const int ring_max = [] { const char* e = getenv("FN2_RING_MAX"); return e ? atoi(e) : 512; }();
+    const char* e_ring = getenv("FN2_RING_MAX");  // tuning knob (read per launch: tools/ab_conv.py toggles it in-process)
+    const int ring_max = e_ring ? atoi(e_ring) : 512;
     const long blocks = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * phases;
     if ((a.dbg & 256) || (blocks >= 384 && blocks <= ring_max)) a.bp64 = 2;
   }
@@ -810,7 +813,8 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
 static int preferred_split(const ConvArgs& a, int tile, int phases) {
   const int bp = tile == 128 ? (a.bp64 ? 64 : 128) : (a.bp64 ? 128 : 256);
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
-  if (blocks >= 384) return 1;
+  const char* e_min = getenv("FN2_SPLIT_MINBLOCKS");  // tuning knob: grids from this many blocks up take no split-K
+  if (blocks >= (e_min ? atoi(e_min) : 384)) return 1;
   // as many splits as still give ONE round of resident blocks (2-3 per CU): rounding up put 528 blocks on 512
   // slots for the 12x16-level layers and a second round of 16 stragglers doubled the kernel time
   const char* e = getenv("FN2_SPLIT_SLOTS");  // tuning knob of the experiments behind the default

@@ -17,12 +17,12 @@ __device__ __forceinline__ void warp3(const float* __restrict__ img, long nb, in
   const int xR = min(xL + 1, W - 1), yB = min(yT + 1, H - 1);
   const float al = x2 - (float)xL, be = y2 - (float)yT;
   const float cTL = (1.f - al) * (1.f - be), cTR = al * (1.f - be), cBL = (1.f - al) * be, cBR = al * be;
-  const float* pTL = img + (nb + (long)yT * W + xL) * 3;
-  const float* pTR = img + (nb + (long)yT * W + xR) * 3;
-  const float* pBL = img + (nb + (long)yB * W + xL) * 3;
-  const float* pBR = img + (nb + (long)yB * W + xR) * 3;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) o[c] = cTL * pTL[c] + cTR * pTR[c] + cBL * pBL[c] + cBR * pBR[c];
+  // 12-byte tap loads (fn2_common.h rgb3_t); same expression per channel as flow_warp_kernel
+  const rgb3_t tl = load_rgb(img + (nb + (long)yT * W + xL) * 3), tr = load_rgb(img + (nb + (long)yT * W + xR) * 3);
+  const rgb3_t bl = load_rgb(img + (nb + (long)yB * W + xL) * 3), br = load_rgb(img + (nb + (long)yB * W + xR) * 3);
+  o[0] = cTL * tl.r + cTR * tr.r + cBL * bl.r + cBR * br.r;
+  o[1] = cTL * tl.g + cTR * tr.g + cBL * bl.g + cBR * br.g;
+  o[2] = cTL * tl.b + cTR * tr.b + cBL * bl.b + cBR * br.b;
 }
 
 template <typename OutT>
@@ -38,11 +38,13 @@ __global__ void __launch_bounds__(256) stack_input_kernel(const float* __restric
     warp3(b, nb, x, y, f.x, f.y, W, H, wv);
     float v[16];
     float e = 0.f;
+    const rgb3_t pa = load_rgb(a + pix * 3), pb = load_rgb(b + pix * 3);
+    const float av3[3] = {pa.r, pa.g, pa.b}, bv3[3] = {pb.r, pb.g, pb.b};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float av = a[pix * 3 + c];
+      const float av = av3[c];
       v[c] = av;
-      v[3 + c] = b[pix * 3 + c];
+      v[3 + c] = bv3[c];
       v[6 + c] = wv[c];
       const float d = av - wv[c];
       e += d * d;
@@ -72,9 +74,11 @@ __global__ void __launch_bounds__(256) fusion_input_kernel(const float* __restri
     warp3(b, nb, x, y, cs.x, cs.y, W, H, wcs);  // flownet2.py:37
     float v[16];
     float esd = 0.f, ecs = 0.f;
+    const rgb3_t pa = load_rgb(a + pix * 3);
+    const float av3[3] = {pa.r, pa.g, pa.b};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float av = a[pix * 3 + c];
+      const float av = av3[c];
       v[c] = av;
       const float d1 = av - wsd[c], d2 = av - wcs[c];
       esd += d1 * d1;

@@ -53,6 +53,15 @@ __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 template <typename T>
 __device__ __forceinline__ void store_elem(T* p, float v) { *p = from_f32<T>(v); }
 
+// Three consecutive floats (an RGB pixel of an NHWC image) as ONE 12-byte access: the 4-byte-aligned packed struct
+// compiles to global_load/store_dwordx3.  The 3-channel passes are bound by vector-memory instruction issue, and this
+// form needs a third of the instructions of per-channel accesses (flow_warp at batch 64: 0.271 -> 0.182 ms).
+struct __attribute__((packed, aligned(4))) rgb3_t { float r, g, b; };
+__device__ __forceinline__ rgb3_t load_rgb(const float* p) { return *reinterpret_cast<const rgb3_t*>(p); }
+__device__ __forceinline__ void store_rgb(float* p, float r, float g, float b) {
+  *reinterpret_cast<rgb3_t*>(p) = rgb3_t{r, g, b};
+}
+
 // Split-fp16 storage element (FN2_F16X2): 4 bytes per logical channel; a group of 8 channels is 8 fp16 hi
 // parts (16 B) followed by 8 fp16 lo parts (16 B).  sizeof == 4 so that all address arithmetic is that of fp32.
 struct x2_t { unsigned raw; };

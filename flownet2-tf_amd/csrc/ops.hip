@@ -185,6 +185,56 @@ __global__ void __launch_bounds__(256) flow_warp_kernel(const float* __restrict_
   }
 }
 
+// Three-channel form (every call site of the networks warps an RGB image): a lane still owns a pixel, but its three
+// channels move as ONE 12-byte access -- a 4-byte-aligned packed struct compiles to global_load/store_dwordx3 -- so a
+// pixel costs 6 memory instructions (flow, four taps, store) instead of 13 (the scalar form above: two loads per tap
+// and three stores).  The pass is bound by vector-memory instruction issue, not by bytes or arithmetic: giving every
+// lane ONE float (coalesced dwords, 6 instructions per 4 output bytes) and dropping the 64-bit index divisions both
+// measured no faster (0.26 ms at batch 64 either way).  UNR pixels per lane are in flight.
+typedef rgb3_t WarpRGB;
+template <int UNR>
+__global__ void __launch_bounds__(256) flow_warp_rgb_kernel(const float* __restrict__ image,
+                                                            const float* __restrict__ flow,
+                                                            float* __restrict__ out, int N, int H, int W) {
+  const long npix = (long)N * H * W;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long p0 = (long)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += stride * UNR) {
+    float2 f[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long pix = p0 + u * stride;
+      f[u] = pix < npix ? *reinterpret_cast<const float2*>(flow + pix * 2) : make_float2(0.f, 0.f);
+    }
+    WarpTaps t[UNR];
+    WarpRGB tl[UNR], tr[UNR], bl[UNR], br[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long pix = p0 + u * stride;
+      const long pc = pix < npix ? pix : 0;
+      const int x = (int)(pc % W);
+      const int y = (int)((pc / W) % H);
+      const long nb = (pc / W / H) * (long)H * W;
+      t[u] = warp_taps(x, y, f[u].x, f[u].y, W, H);
+      tl[u] = *reinterpret_cast<const WarpRGB*>(image + (nb + (long)t[u].yT * W + t[u].xL) * 3);
+      tr[u] = *reinterpret_cast<const WarpRGB*>(image + (nb + (long)t[u].yT * W + t[u].xR) * 3);
+      bl[u] = *reinterpret_cast<const WarpRGB*>(image + (nb + (long)t[u].yB * W + t[u].xL) * 3);
+      br[u] = *reinterpret_cast<const WarpRGB*>(image + (nb + (long)t[u].yB * W + t[u].xR) * 3);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long pix = p0 + u * stride;
+      if (pix >= npix) continue;
+      WarpRGB o = {0.f, 0.f, 0.f};
+      if (t[u].valid) {  // :82-86, same expression per channel as the scalar form
+        o.r = t[u].cTL * tl[u].r + t[u].cTR * tr[u].r + t[u].cBL * bl[u].r + t[u].cBR * br[u].r;
+        o.g = t[u].cTL * tl[u].g + t[u].cTR * tr[u].g + t[u].cBL * bl[u].g + t[u].cBR * br[u].g;
+        o.b = t[u].cTL * tl[u].b + t[u].cTR * tr[u].b + t[u].cBL * bl[u].b + t[u].cBR * br[u].b;
+      }
+      *reinterpret_cast<WarpRGB*>(out + pix * 3) = o;
+    }
+  }
+}
+
 // flow_warp backward (flow_warp_grad.cu.cc:30-86).  image_grad must be zeroed by the caller
 // (hipMemsetAsync on the same stream in the launcher); flow_grad is written for every pixel.
 __global__ void __launch_bounds__(256) flow_warp_grad_kernel(const float* __restrict__ image,
@@ -399,6 +449,37 @@ __global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __res
   }
 }
 
+// Two-channel form (the flow fields: every caller in the networks): a lane owns two adjacent output pixels -- one
+// 16-byte store, eight 8-byte tap loads (neighbouring outputs share taps: L1 hits).  Same arithmetic per element.
+__global__ void __launch_bounds__(256) resize_bilinear_c2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 int N, int Hin, int Win, int oh, int ow, float sy,
+                                                                 float sx, float scale) {
+  // block = (output row blockIdx.y, 256 pixel pairs of it): no per-element 64-bit divisions
+  const int y = blockIdx.y % oh, n = blockIdx.y / oh;
+  const int xp = blockIdx.x * 256 + threadIdx.x;
+  if (2 * xp >= ow) return;
+  const float fy = (float)y * sy;
+  const int y0 = (int)floorf(fy);
+  const int y1 = min(y0 + 1, Hin - 1);
+  const float ly = fy - (float)y0;
+  const float2* r0 = reinterpret_cast<const float2*>(in) + ((long)n * Hin + y0) * Win;
+  const float2* r1 = reinterpret_cast<const float2*>(in) + ((long)n * Hin + y1) * Win;
+  float res[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float fx = (float)(2 * xp + j) * sx;
+    const int x0 = (int)floorf(fx);
+    const int x1 = min(x0 + 1, Win - 1);
+    const float lx = fx - (float)x0;
+    const float2 tl = r0[x0], tr = r0[x1], bl = r1[x0], br = r1[x1];
+    const float top0 = tl.x + (tr.x - tl.x) * lx, bot0 = bl.x + (br.x - bl.x) * lx;
+    const float top1 = tl.y + (tr.y - tl.y) * lx, bot1 = bl.y + (br.y - bl.y) * lx;
+    res[2 * j] = (top0 + (bot0 - top0) * ly) * scale;
+    res[2 * j + 1] = (top1 + (bot1 - top1) * ly) * scale;
+  }
+  *reinterpret_cast<float4*>(out + ((long)blockIdx.y * ow + 2 * xp) * 2) = make_float4(res[0], res[1], res[2], res[3]);
+}
+
 static inline int grid_for(long work_items, int block) {
   long g = (work_items + block - 1) / block;
   if (g > 256L * 16) g = 256L * 16;  // 256 CUs x 16 blocks, grid-stride the rest
@@ -488,8 +569,8 @@ int fn2_flow_warp_f32(const float* image, const float* flow, float* out, int n, 
   FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "Input images must have rank 4");  // flow_warp.cc:22
   const long npix = (long)n * h * w;
   if (c == 3)
-    hipLaunchKernelGGL(flow_warp_kernel<3>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, image,
-                       flow, out, n, h, w, c);
+    hipLaunchKernelGGL(flow_warp_rgb_kernel<2>, dim3(grid_for(npix / 2, 256)), dim3(256), 0, (hipStream_t)stream, image, flow,
+                       out, n, h, w);
   else
     hipLaunchKernelGGL(flow_warp_kernel<0>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, image,
                        flow, out, n, h, w, c);
@@ -540,8 +621,12 @@ int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in
   const float sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
   const float sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
   const long total = (long)n * out_h * out_w;
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
-                     out, n, in_h, in_w, c, out_h, out_w, sy, sx, scale);
+  if (c == 2 && out_w % 2 == 0 && (long)n * out_h <= 65535)
+    hipLaunchKernelGGL(resize_bilinear_c2_kernel, dim3((out_w / 2 + 255) / 256, n * out_h), dim3(256), 0,
+                       (hipStream_t)stream, in, out, n, in_h, in_w, out_h, out_w, sy, sx, scale);
+  else
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, n, in_h, in_w, c, out_h, out_w, sy, sx, scale);
   FN2_CHECK_LAUNCH("resize_bilinear");
   return FN2_OK;
 }

@@ -111,7 +111,8 @@ def test_flow_warp_validation(surf):
 
 
 # ---- downsample -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape,size", [((2, 64, 96, 2), (4, 6)), ((1, 64, 96, 2), (16, 24)),
+@pytest.mark.parametrize("shape,size", [((2, 64, 96, 2), (4, 6)), ((1, 64, 96, 2), (16, 24)), ((3, 64, 96, 1), (4, 6)),
+                                        ((1, 70, 100, 2), (5, 13)), ((2, 48, 64, 3), (3, 4)),
                                         ((1, 13, 17, 3), (5, 4)), ((1, 8, 8, 2), (8, 8)),
                                         ((1, 200, 40, 16), (3, 30))])  # last: window too large for LDS -> generic kernel
 def test_downsample_matches_oracle(surf, shape, size):

@@ -21,7 +21,9 @@ LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch
     "conv2": ("conv", 5, 2, 2, 64, 128, 8, 192, 256),
     "conv3": ("conv", 5, 2, 2, 128, 256, 8, 96, 128),
     "conv3_1": ("conv", 3, 1, 1, 256, 256, 8, 48, 64),
+    "conv4": ("conv", 3, 2, 1, 256, 512, 8, 48, 64),
     "conv4_1": ("conv", 3, 1, 1, 512, 512, 8, 24, 32),
+    "conv5": ("conv", 3, 2, 1, 512, 512, 8, 24, 32),
     "conv5_1": ("conv", 3, 1, 1, 512, 512, 8, 12, 16),
     "conv6": ("conv", 3, 2, 1, 512, 1024, 8, 12, 16),
     "conv6_1": ("conv", 3, 1, 1, 1024, 1024, 8, 6, 8),
@@ -105,7 +107,7 @@ def main():
         libs.append(l)
     variants = [v for v in a.variants.split(",")]
     for name in a.layers.split(","):
-        for kv in ("FN2_BP64_MIN", "FN2_SPLIT_SLOTS", "FN2_CONV_DBG"):
+        for kv in ("FN2_BP64_MIN", "FN2_SPLIT_SLOTS", "FN2_CONV_DBG", "FN2_RING_MAX", "FN2_SPLIT_MINBLOCKS"):
             os.environ.pop(kv, None)
         d, flop, keep = build(name, a.dtype)
         times = {v: [] for v in variants}
@@ -116,7 +118,7 @@ def main():
                 # "dbg/KEY=VAL/KEY=VAL": extra environment knobs of the library for this variant
                 parts = dbg.split("/")
                 dbg = parts[0]
-                for kv in ("FN2_BP64_MIN", "FN2_SPLIT_SLOTS"):
+                for kv in ("FN2_BP64_MIN", "FN2_SPLIT_SLOTS", "FN2_RING_MAX", "FN2_SPLIT_MINBLOCKS"):
                     os.environ.pop(kv, None)
                 for kv in parts[1:]:
                     k_, v_ = kv.split("=")
