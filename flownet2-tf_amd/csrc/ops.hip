@@ -346,6 +346,30 @@ __global__ void __launch_bounds__(256) downsample_sep_kernel(const float* __rest
   const float srcy = ((float)dy / (float)(oh - 1)) * (float)(Hin - 1);
   const int iy = (int)roundf(srcy);
   const int wh = 2 * hr + 1, ww = 2 * wr + 1, rowlen = ow * C;
+  if (C == 2) {
+    // two-channel tensors (the flow fields the loss downsamples): a lane owns both channels of a (window row, dx)
+    // and reads each tap as ONE 8-byte load -- the pass is bound by memory-instruction issue (see flow_warp)
+    for (int item = threadIdx.x; item < wh * ow; item += blockDim.x) {
+      const int r = item / ow, dx = item - r * ow;
+      const int yo = iy - hr + r;
+      float av0 = 0.f, aw0 = 0.f, an0 = 0.f, av1 = 0.f, aw1 = 0.f, an1 = 0.f;
+      if (yo >= 0 && yo < Hin) {
+        const float srcx = ((float)dx / (float)(ow - 1)) * (float)(Win - 1);
+        const int ix = (int)roundf(srcx);
+        const float2* p = reinterpret_cast<const float2*>(in) + ((long)n * Hin + yo) * Win;
+        for (int k = 0; k < ww; ++k) {
+          const int xo = ix - wr + k;
+          if (xo < 0 || xo >= Win) continue;
+          const float wgt = fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale);
+          const float2 sv = p[xo];
+          if (sv.x != sv.x) an0 += wgt; else { av0 += sv.x * wgt; aw0 += wgt; }
+          if (sv.y != sv.y) an1 += wgt; else { av1 += sv.y * wgt; aw1 += wgt; }
+        }
+      }
+      float* q = rows + ((long)r * rowlen + dx * 2) * 3;
+      q[0] = av0; q[1] = aw0; q[2] = an0; q[3] = av1; q[4] = aw1; q[5] = an1;
+    }
+  } else
   for (int item = threadIdx.x; item < wh * rowlen; item += blockDim.x) {
     const int r = item / rowlen, e = item - r * rowlen;
     const int dx = e / C, c = e - dx * C;
@@ -402,6 +426,12 @@ __global__ void __launch_bounds__(1024) downsample_wide_kernel(const float* __re
       const int xo = ix - wr + k;
       if (xo < 0 || xo >= Win) continue;
       const float wgt = wy * fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale);
+      if (C == 2) {  // both channels of a tap as one 8-byte load
+        const float2 sv = reinterpret_cast<const float2*>(p)[xo];
+        if (sv.x != sv.x) an[0] += wgt; else { av[0] += sv.x * wgt; aw[0] += wgt; }
+        if (sv.y != sv.y) an[1] += wgt; else { av[1] += sv.y * wgt; aw[1] += wgt; }
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (c < C) {
