@@ -39,8 +39,11 @@ def conv2_kernel_args(tile, m, cout_pad, phases):
         return _TILE_ARGS[tile]
     if tile < 128:
         return {64: "1, 4, 2, 1", 32: "1, 4, 1, 1"}[tile]
-    if -(-m // 64) * (cout_pad // 128) * phases >= int(os.environ.get("FN2_BP64_MIN", "96")):
-        return "2, 2, 2, 1"
+    blocks = -(-m // 64) * (cout_pad // 128) * phases
+    if blocks >= int(os.environ.get("FN2_BP64_MIN", "96")):
+        # 128 x 64 tiles; the 3-slot ring instantiation (STAGES = 3) for one-round grids without split-K (conv.hip)
+        ring = 384 <= blocks <= int(os.environ.get("FN2_RING_MAX", "512"))
+        return "2, 2, 2, 1, 3" if ring else "2, 2, 2, 1, 2"
     return _TILE_ARGS[tile]
 
 
@@ -124,8 +127,12 @@ class Engine:
         sbuf, sc0, sc = src
         dbuf, dc0, dc = dst
         assert sc == cin and dc == cout, (scope, name, sc, cin, dc, cout)
+        # small heads (6x8 .. 24x32 levels at batch 8): the one-launch wave-per-pixel kernel; the GEMM + gather pair is
+        # two launches of a handful of blocks there.  FN2_HEAD_GEMM_MIN = pixels from which the GEMM form is used.
+        head_px = dbuf.shape[0] * dbuf.shape[1] * dbuf.shape[2]
         if (self.heads_as_gemm and kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1 and not act
-                and dbuf.dtype == torch.float32 and self._head_gemm(scope, spec, src, dst)):
+                and dbuf.dtype == torch.float32 and head_px >= int(os.environ.get("FN2_HEAD_GEMM_MIN", "8192"))
+                and self._head_gemm(scope, spec, src, dst)):
             return
         wname = f"{scope}/{name}/weights"
         in_code = self._code(sbuf)
