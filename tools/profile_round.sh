@@ -33,7 +33,7 @@ pmc() {  # name, counter, bench args...
   rocprofv3 --kernel-trace --pmc $counter -d $out/pmc_${name}_$counter --output-format csv -- python $root/bench.py "$@" \
       --no-cpu-baseline --no-graph --steps 3 --warmup 1 > /dev/null 2> $out/pmc_${name}_$counter.err
 }
-for cfg in "FlowNetC_b8_f16x2 --dtype f16x2" "FlowNetC_b8_f32 --dtype f32"; do
+for cfg in "FlowNetC_b8_f16x2 --dtype f16x2" "FlowNetC_b8_f32 --dtype f32" "FlowNet2_b4_f16x2 --model FlowNet2 --batch 4 --dtype f16x2"; do
   set -- $cfg
   name=$1; shift
   pmc $name FETCH_SIZE "$@"
