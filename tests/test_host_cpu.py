@@ -3,6 +3,7 @@ declares, argument validation that needs no device, weight packing, harness logi
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -246,3 +247,26 @@ def test_caffe_converter_npy_is_ingested(tmp_path):
     np.save(tmp_path / "bad.npy", np.zeros(3))
     with pytest.raises(ValueError):
         W.load_npy(str(tmp_path / "bad.npy"))
+
+
+def test_bench_traffic_lookup_resolves_committed_profiles():
+    """bench.py's roofline.traffic comes from the committed PMC summaries: the kernel names the engine reports must
+    resolve in them (a renamed instantiation silently turned the field into null once)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    for model, batch in (("FlowNetC", 8), ("FlowNet2", 4)):
+        path = os.path.join(ROOT, "profiles", "pmc_traffic_%s_b%d_f16x2.json" % (model, batch))
+        if not os.path.exists(path):
+            continue
+        line = json.load(open(os.path.join(ROOT, "profiles", "r01_%s_b%d_f16x2_bench.json" % (model.lower(), batch))))
+        kern = line["roofline"]["kernel"]
+        got = bench.stored_traffic(model, batch, "f16x2", kern)
+        assert got is not None and got > 1e6, (model, kern)
+    assert bench.stored_traffic("FlowNetC", 8, "f16x2", "no_such_kernel<1>") is None
