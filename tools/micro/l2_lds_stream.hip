@@ -20,7 +20,9 @@ __device__ __forceinline__ void dma16(const v4i rsrc, const void* lds, unsigned 
                :: "s"(la), "v"(voff), "s"(rsrc), "s"(so) : "memory");
 }
 
-template <int PIECES>
+// HALF: a piece is 16 rows x 64 B (the lower or upper half of sixteen 128-byte lines, alternating by stage) instead
+// of 8 whole lines -- what a 64-byte-row (16 split-fp16 channels per stage) variant of the conv loop would fetch
+template <int PIECES, bool HALF = false>
 __global__ void __launch_bounds__(256) stream_kernel(const char* buf, int window_bytes, int stages, int* sink) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -32,21 +34,28 @@ __global__ void __launch_bounds__(256) stream_kernel(const char* buf, int window
   auto issue = [&](int h) {
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
-      const unsigned o = (off + (unsigned)((wave * PIECES + p) * 1024)) % (unsigned)window_bytes;
-      dma16(rs, lds + h * half + (wave * PIECES + p) * 1024, (unsigned)(lane * 16), (int)o);
+      if constexpr (HALF) {
+        const unsigned o = (off + (unsigned)((wave * PIECES + p) * 2048)) % (unsigned)window_bytes;
+        dma16(rs, lds + h * half + (wave * PIECES + p) * 1024, (unsigned)((lane >> 2) * 128 + (lane & 3) * 16 + h * 64), (int)o);
+      } else {
+        const unsigned o = (off + (unsigned)((wave * PIECES + p) * 1024)) % (unsigned)window_bytes;
+        dma16(rs, lds + h * half + (wave * PIECES + p) * 1024, (unsigned)(lane * 16), (int)o);
+      }
     }
-    off = (off + half) % (unsigned)window_bytes;
+    if (!HALF || h == 1) off = (off + (HALF ? 2 * half : half)) % (unsigned)window_bytes;
   };
   issue(0);
   for (int s = 0; s < stages; s += 2) {
     issue(1);
     if (PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (PIECES == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(0);
     if (PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (PIECES == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -57,25 +66,25 @@ __global__ void __launch_bounds__(256) stream_kernel(const char* buf, int window
   if (sink != nullptr && threadIdx.x == 0) sink[blockIdx.x] = ((int*)lds)[blockIdx.x & 63];
 }
 
-template <int PIECES>
+template <int PIECES, bool HALF = false>
 static void run(const char* buf, int window, int blocks_per_cu, int cus, int* sink) {
   const int stages = 400;
   const size_t lds = 2 * 4 * PIECES * 1024;
-  hipFuncSetAttribute((const void*)stream_kernel<PIECES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)stream_kernel<PIECES, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int grid = blocks_per_cu * cus;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(stream_kernel<PIECES>, dim3(grid), dim3(256), lds, 0, buf, window, stages, sink);
+    hipLaunchKernelGGL((stream_kernel<PIECES, HALF>), dim3(grid), dim3(256), lds, 0, buf, window, stages, sink);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
   }
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   const double bytes = (double)grid * (stages + 1) * 4 * PIECES * 1024;
-  printf("{\"pieces_per_wave_stage\": %d, \"blocks_per_cu\": %d, \"kb_in_flight_per_cu\": %d, \"window_mb\": %.1f, \"ms\": %.4f, \"TB_per_s\": %.2f}\n",
-         PIECES, blocks_per_cu, 2 * 4 * PIECES * blocks_per_cu, window / 1048576.0, ms, bytes / ms / 1e9);
+  printf("{\"half_lines\": %d, \"pieces_per_wave_stage\": %d, \"blocks_per_cu\": %d, \"kb_in_flight_per_cu\": %d, \"window_mb\": %.1f, \"ms\": %.4f, \"TB_per_s\": %.2f}\n",
+         (int)HALF, PIECES, blocks_per_cu, 2 * 4 * PIECES * blocks_per_cu, window / 1048576.0, ms, bytes / ms / 1e9);
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
@@ -94,6 +103,7 @@ int main() {
       run<4>(buf, window, bpc, cus, sink);
       run<6>(buf, window, bpc, cus, sink);
       if (bpc <= 2) run<12>(buf, window, bpc, cus, sink);
+      if (bpc == 3) { run<3, true>(buf, window, bpc, cus, sink); run<6, true>(buf, window, bpc, cus, sink); }
     }
   }
   hipFree(buf); hipFree(sink);
