@@ -131,6 +131,67 @@ __global__ void __launch_bounds__(256) correlation_grad_kernel(
   }
 }
 
+// Tiled form for the FlowNetC call site (kernel_size 1, stride_1 1, pad = max_displacement: flownet_c.py:40), where
+// the reference's window sums collapse to one element:
+//   dA[n,y,x,c] = (1/C) sum_{p,o} g[n,y,x,(p,o)]           * B0[n, y+s2 p, x+s2 o, c]
+//   dB[n,y,x,c] = (1/C) sum_{p,o} g[n,y-s2 p,x-s2 o,(p,o)] * A0[n, y-s2 p, x-s2 o, c]      (zero outside the image)
+// A block owns 16 pixels of a row, a lane one channel.  Per displacement row the lane loads its channel of the 56
+// window pixels ONCE (coalesced over channels) and reuses it for the 16 x 21 (pixel, o) products; the gradient
+// values are block-uniform LDS broadcasts.  The thread-per-element kernel above re-loads the window for every
+// output pixel: 7.3 ms at batch 8 against 0.16 ms for the forward op.  Same accumulation order per output.
+template <bool DA, int TILE, int GR, int S2>
+__global__ void __launch_bounds__(256) correlation_grad_tiled_kernel(const float* __restrict__ g,
+                                                                     const float* __restrict__ src,
+                                                                     float* __restrict__ dst, int N, int H, int W,
+                                                                     int C) {
+  constexpr int GW = 2 * GR + 1, D = GW * GW, MD = GR * S2, WIN = TILE + 2 * MD;
+  __shared__ float gs[DA ? TILE * D : WIN * GW];
+  const int cblocks = (C + 255) / 256;
+  const int n = blockIdx.z / cblocks, c = (blockIdx.z % cblocks) * 256 + threadIdx.x;
+  const int y = blockIdx.y, x0 = blockIdx.x * TILE;
+  const bool c_ok = c < C;
+  float acc[TILE];
+#pragma unroll
+  for (int i = 0; i < TILE; ++i) acc[i] = 0.f;
+  if constexpr (DA) {
+    for (int i = threadIdx.x; i < TILE * D; i += 256) {
+      const int px = i / D, d = i - px * D;
+      gs[i] = (x0 + px < W) ? g[(((long)n * H + y) * W + x0 + px) * D + d] : 0.f;
+    }
+    __syncthreads();
+  }
+  for (int p = 0; p < GW; ++p) {
+    const int ys = DA ? y + (p - GR) * S2 : y - (p - GR) * S2;  // block-uniform
+    if (ys < 0 || ys >= H) continue;
+    if constexpr (!DA) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < WIN * GW; i += 256) {
+        const int j = i / GW, o = i - j * GW;
+        const int xa = x0 - MD + j;
+        gs[i] = (xa >= 0 && xa < W) ? g[(((long)n * H + ys) * W + xa) * D + p * GW + o] : 0.f;
+      }
+      __syncthreads();
+    }
+    float win[WIN];
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+      const int xw = x0 - MD + j;
+      win[j] = (c_ok && xw >= 0 && xw < W) ? src[(((long)n * H + ys) * W + xw) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < GW; ++o)
+#pragma unroll
+      for (int px = 0; px < TILE; ++px) {
+        if constexpr (DA) acc[px] += gs[px * D + p * GW + o] * win[px + S2 * o];
+        else acc[px] += gs[(px + 2 * MD - S2 * o) * GW + o] * win[px + 2 * MD - S2 * o];
+      }
+  }
+  if (c_ok)
+#pragma unroll
+    for (int px = 0; px < TILE; ++px)
+      if (x0 + px < W) dst[(((long)n * H + y) * W + x0 + px) * C + c] = acc[px] / (float)C;
+}
+
 // ---------------------------------------------------------------------------
 // flow_warp (flow_warp.cu.cc:44-95): one lane per pixel, all channels in the lane.
 // ---------------------------------------------------------------------------
@@ -587,6 +648,16 @@ int fn2_correlation_grad_f32(const float* g, const float* a, const float* b, flo
   int rc = correlation_geometry(h, w, k, md, s1, s2, pad, &oh, &ow, &gr, &gw);
   if (rc) return rc;
   const long total = (long)n * h * w * c;
+  if (k == 1 && s1 == 1 && s2 == 2 && md == 20 && pad == md && (long)n * ((c + 255) / 256) <= 65535 && h <= 65535) {
+    // the FlowNetC attribute set: tiled kernels, one launch per gradient
+    const dim3 grid((w + 15) / 16, h, n * ((c + 255) / 256));
+    hipLaunchKernelGGL((correlation_grad_tiled_kernel<true, 16, 10, 2>), grid, dim3(256), 0, (hipStream_t)stream, g, b, da,
+                       n, h, w, c);
+    hipLaunchKernelGGL((correlation_grad_tiled_kernel<false, 16, 10, 2>), grid, dim3(256), 0, (hipStream_t)stream, g, a, db,
+                       n, h, w, c);
+    FN2_CHECK_LAUNCH("correlation_grad_tiled");
+    return FN2_OK;
+  }
   hipLaunchKernelGGL(correlation_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      g, a, b, da, db, n, h, w, c, k, md, s1, s2, pad, oh, ow, gr, gw);
   FN2_CHECK_LAUNCH("correlation_grad");

@@ -53,7 +53,11 @@ def test_correlation_validation(surf):
 
 
 @pytest.mark.parametrize("shape,args", [((1, 5, 6, 4), (1, 2, 1, 1, 2)), ((2, 6, 7, 3), (1, 4, 1, 2, 4)),
-                                        ((1, 6, 7, 2), (3, 2, 2, 1, 3))])
+                                        ((1, 6, 7, 2), (3, 2, 2, 1, 3)),
+                                        # the FlowNetC attribute set (flownet_c.py:40) -> the tiled kernels: ragged
+                                        # 16-pixel tiles, rows displaced out of the image, C < 256 and C > 256
+                                        ((2, 11, 37, 40), (1, 20, 1, 2, 20)), ((1, 5, 18, 300), (1, 20, 1, 2, 20)),
+                                        ((1, 48, 64, 8), (1, 20, 1, 2, 20))])
 def test_correlation_grad_matches_oracle(surf, shape, args):
     a, b = rnd(shape, 2), rnd(shape, 3)
     g = rnd(ref.correlation(a, b, *args).shape, 4)
@@ -62,8 +66,9 @@ def test_correlation_grad_matches_oracle(surf, shape, args):
     tb = torch.from_numpy(b).cuda().requires_grad_(True)
     out = surf[0](ta, tb, *args)
     out.backward(torch.from_numpy(g).cuda())
-    np.testing.assert_allclose(ta.grad.cpu().numpy(), da, rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(tb.grad.cpu().numpy(), db, rtol=1e-5, atol=2e-6)
+    atol = 2e-6 if args[1] < 20 else 1e-5  # 441-term fp32 sums with cancellation at the FlowNetC attributes
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), da, rtol=1e-5, atol=atol)
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), db, rtol=1e-5, atol=atol)
 
 
 # ---- flow_warp ----------------------------------------------------------------------------------

@@ -62,10 +62,19 @@ def main():
     ms = timed(lambda: _hip.check(lib.fn2_correlation_f32(P_(fa), P_(fb), P_(co), N, h8, w8, 256, 1, 20, 1, 2, 20, st())),
                a.rounds, a.inner)
     rec("correlation_f32", ms, N * h8 * w8 * (2 * 256 + 441) * 4, "read A, B once + write 441 channels")
+    # the backward ops of SURVEY 8(a) row a12 (used only when a network with these ops is trained)
+    gco, gda, gdb = rnd(N, h8, w8, 441), buf(N, h8, w8, 256), buf(N, h8, w8, 256)
+    ms = timed(lambda: _hip.check(lib.fn2_correlation_grad_f32(P_(gco), P_(fa), P_(fb), P_(gda), P_(gdb), N, h8, w8, 256,
+                                                                 1, 20, 1, 2, 20, st())), max(3, a.rounds // 3), 2)
+    rec("correlation_grad_f32", ms, N * h8 * w8 * (4 * 256 + 441) * 4, "read grad, A, B once + write dA, dB")
     # flow_warp at full resolution
     img, flow, wo = rnd(N, H, W, 3), rnd(N, H, W, 2) * 4, buf(N, H, W, 3)
     ms = timed(lambda: _hip.check(lib.fn2_flow_warp_f32(P_(img), P_(flow), P_(wo), N, H, W, 3, st())), a.rounds, a.inner)
     rec("flow_warp_f32", ms, N * H * W * (3 + 2 + 3) * 4, "image + flow + output")
+    gwo, gimg, gflow = rnd(N, H, W, 3), buf(N, H, W, 3), buf(N, H, W, 2)
+    ms = timed(lambda: _hip.check(lib.fn2_flow_warp_grad_f32(P_(img), P_(flow), P_(gwo), P_(gimg), P_(gflow), N, H, W, 3, st())),
+               a.rounds, a.inner)
+    rec("flow_warp_grad_f32", ms, N * H * W * (3 + 2 + 3 + 3 + 2) * 4, "image, flow, grad + image_grad (zeroed, atomics), flow_grad")
     # downsample of the ground-truth flow to the coarsest and finest loss scales
     gt = rnd(N, H, W, 2)
     for lvl in (6, 2):
