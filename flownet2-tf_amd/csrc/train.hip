@@ -827,9 +827,20 @@ int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* str
 
 int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream) {
   FN2_REQUIRE(g && g->data && db, "bias_grad: null pointer");
-  FN2_REQUIRE(g->dtype == FN2_F32, "bias_grad: fp32 only");
+  FN2_REQUIRE(g->dtype == FN2_F32 || g->dtype == FN2_F16X2, "bias_grad: fp32 or split-fp16 gradients");
   const long npix = (long)g->n * g->h * g->w;
   hipStream_t st = (hipStream_t)stream;
+  if (g->dtype == FN2_F16X2) {
+    // linear layers with a bias in the split-fp16 trainer (FlowNetSD's interconvN): the LeakyReLU pass without the
+    // activation factor
+    FN2_REQUIRE(g->c % 8 == 0 && g->cs % 8 == 0 && g->c0 % 8 == 0, "bias_grad: split-fp16 slices are group (8) aligned");
+    const int l2x = gpb_log2_for(g->c / 8);
+    const int sp = bias_splits(npix, l2x);
+    hipLaunchKernelGGL(act_bias_bwd_x2_kernel<false>, dim3((g->c / 8 + (1 << l2x) - 1) >> l2x, (int)sp), dim3(256), 0, st,
+                       (const x2_t*)nullptr, (x2_t*)g->data, db, npix, g->c, 0, 0, g->cs, g->c0, l2x);
+    FN2_CHECK_LAUNCH("bias_grad");
+    return FN2_OK;
+  }
   if (g->c == 2 && g->cs == 2 && g->c0 == 0) {
     hipLaunchKernelGGL(bias_grad2_kernel, dim3(grid_for(npix, 1024)), dim3(256), 0, st, (const float*)g->data, db, npix);
   } else if (g->c % 4 == 0 && g->cs % 4 == 0 && g->c0 % 4 == 0) {

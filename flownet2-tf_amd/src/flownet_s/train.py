@@ -32,8 +32,8 @@ def unpack_weights(trainer):
     return out
 
 
-def save_checkpoint(out_dir, step, weights, fmt="npz"):
-    """npz: flownet_s-<step>.npz.  tf: model.ckpt-<step>.{index,data-00000-of-00001} + the `checkpoint` state file,
+def save_checkpoint(out_dir, step, weights, fmt="npz", stem="flownet_s"):
+    """npz: <stem>-<step>.npz (flownet_s-<step>.npz / flownet_sd-<step>.npz).  tf: model.ckpt-<step>.{index,data-00000-of-00001} + the `checkpoint` state file,
     the files the reference's slim Saver leaves in its log dir (net.py:1386-1392) and that both this package and
     tf.train.Saver.restore read (variables under the reference names + global_step)."""
     from .. import weights as W
@@ -44,7 +44,7 @@ def save_checkpoint(out_dir, step, weights, fmt="npz"):
         with open(os.path.join(out_dir, "checkpoint"), "w") as f:
             f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
         return os.path.join(out_dir, name)
-    path = os.path.join(out_dir, "flownet_s-%d.npz" % step)
+    path = os.path.join(out_dir, "%s-%d.npz" % (stem, step))
     W.save_npz(path, weights)
     return path
 
@@ -59,10 +59,11 @@ def main(flags):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("FN2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    wts = W.load_weights(flags.checkpoint) if flags.checkpoint else W.init_weights("FlowNetS", flags.seed)
+    model = getattr(flags, "model", "FlowNetS")
+    wts = W.load_weights(flags.checkpoint) if flags.checkpoint else W.init_weights(model, flags.seed)
     pre = FLYING_CHAIRS_PREPROCESS
     h, w = (pre["crop_height"], pre["crop_width"]) if flags.augment else (flags.height, flags.width)
-    tr = FlowNetSTrainer(wts, flags.batch, h, w, schedule=LONG_SCHEDULE, dtype=flags.dtype)
+    tr = FlowNetSTrainer(wts, flags.batch, h, w, schedule=LONG_SCHEDULE, dtype=flags.dtype, model=model)
     os.makedirs(flags.out, exist_ok=True)
     t0 = time.perf_counter()
     for step, (a, b, f) in enumerate(load_batches(flags.list, flags.batch, pre, flags.augment, seed=flags.seed + rank), 1):
@@ -73,13 +74,13 @@ def main(flags):
                 print("global step %6d | loss %.5f | %.1f pairs/s" % (step, val, world * flags.batch * step /
                                                                       (time.perf_counter() - t0)), flush=True)
         if rank == 0 and (step % flags.save_every == 0 or step == flags.steps):
-            save_checkpoint(flags.out, step, unpack_weights(tr), flags.ckpt_format)
+            save_checkpoint(flags.out, step, unpack_weights(tr), flags.ckpt_format, stem=model.lower().replace("net", "net_"))
         if step >= flags.steps:
             break
     return tr
 
 
-if __name__ == "__main__":
+def parse_and_run(model):
     ap = argparse.ArgumentParser()
     ap.add_argument("--list", required=True, help="text file of `image_a image_b flow.flo` triples, or a .tfrecords file of the "
                                                   "reference's converter (python -m src.tfrecord builds one)")
@@ -98,6 +99,11 @@ if __name__ == "__main__":
     ap.add_argument("--save-every", type=int, default=1000)
     ap.add_argument("--report-l2", action="store_true", help="add the L2 regulariser to the printed loss")
     FLAGS = ap.parse_args()
+    FLAGS.model = model
     if not os.path.exists(FLAGS.list):
         raise ValueError("list path must exist")
-    main(FLAGS)
+    return main(FLAGS)
+
+
+if __name__ == "__main__":
+    parse_and_run("FlowNetS")

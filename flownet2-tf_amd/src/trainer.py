@@ -1,4 +1,5 @@
-"""FlowNetS training step on one MI355X (+ data-parallel gradient all-reduce over RCCL):
+"""FlowNetS / FlowNetSD training step on one MI355X (+ data-parallel gradient all-reduce over RCCL; FlowNetSD:
+``model="FlowNetSD"``, labels 20 * gt as flownet_sd.py:122, linear interconvN layers before the heads):
 forward -> multiscale EPE loss -> backward -> Adam, all fp32 on the matrix cores.
 
 Reference semantics (what tf.gradients + tf.train.AdamOptimizer compute for it):
@@ -51,7 +52,7 @@ def _index_hwio(rec):
 
 
 class FlowNetSTrainer:
-    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8, dtype="f32"):
+    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8, dtype="f32", model="FlowNetS"):
         """dtype 'f32': everything on the fp32 matrix cores.  'f16x2': activations, activation gradients and the
         weight copies the convolutions read are split fp16 (3 fp16 MFMAs per product, fp32 accumulate); the master
         weights, their gradients and the Adam state stay fp32."""
@@ -64,7 +65,12 @@ class FlowNetSTrainer:
         self.loss_scale = 16384.0 if self.x2 else 1.0
         self.code = _hip.FN2_F16X2 if self.x2 else F32
         self.host_weights = weights
-        self.eng = Engine("FlowNetS", weights, batch, height, width, dtype, heads_as_gemm=False)
+        if model not in ("FlowNetS", "FlowNetSD"):
+            raise ValueError("the trainer covers the networks without correlation / flow_warp: FlowNetS, FlowNetSD")
+        self.model = model
+        # label scale of the loss: 0.05 * gt for FlowNetS (flownet_s.py:123), 20 * gt for FlowNetSD (flownet_sd.py:122)
+        self.gt_scale = 20.0 if model == "FlowNetSD" else 0.05
+        self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False)
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
         self.schedule, self.eps = schedule, eps
@@ -333,7 +339,7 @@ class FlowNetSTrainer:
         self.loss_dev.zero_()
         eng.launch()
         # ---- loss and its gradient at the five scales (flownet_s.py:122-158)
-        gts = self.gt * 0.05
+        gts = self.gt * self.gt_scale
         for lvl, wgt in LOSS_WEIGHTS.items():
             pred = eng.outputs["predict_flow%d" % lvl]
             n, h, w, _ = pred.shape

@@ -16,12 +16,19 @@ LOSS_WEIGHTS = {6: 0.32, 5: 0.08, 4: 0.02, 3: 0.01, 2: 0.005}
 
 
 def _leaky(x, positive=None):
+    """utils.py:401-405: 0.55 x + 0.45 |x|.  ``positive``: the branch the device took per element -- a bool array
+    (True = output > 0) or a sign array (+1 / -1 / 0: an output that is EXACTLY 0 differentiates as 0.55, tf.abs' =
+    sign(0) = 0, which is also what the device's backward pass applies)."""
     if positive is not None:
-        return torch.where(torch.as_tensor(positive).permute(0, 3, 1, 2), x, 0.1 * x)
+        sg = torch.as_tensor(np.asarray(positive)).permute(0, 3, 1, 2)
+        if sg.dtype == torch.bool:
+            return torch.where(sg, x, 0.1 * x)
+        return torch.where(sg > 0, x, torch.where(sg < 0, 0.1 * x, 0.55 * x))
     return 0.55 * x + 0.45 * x.abs()  # utils.py:401-405
 
 
-def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS", l2=0.0, act_grads=None, signs=None):
+def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS", l2=0.0, act_grads=None, signs=None,
+                             model="FlowNetS"):
     """Returns (loss, {variable name: gradient in the reference layout}, predictions).  l2 > 0 adds the slim
     regulariser 0.5*l2*|W|^2 of the slim.conv2d weights to the loss (and so l2*W to their gradients).
     act_grads: optional dict, filled with {layer name: dLoss/d(layer output), NHWC} for debugging.
@@ -54,9 +61,16 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
     a = torch.tensor(np.asarray(input_a, np.float64)).permute(0, 3, 1, 2)
     b = torch.tensor(np.asarray(input_b, np.float64)).permute(0, 3, 1, 2)
     x = torch.cat([a, b], 1)
-    c1 = conv(x, "conv1", 2, 3)
-    c2 = conv(c1, "conv2", 2, 2)
-    c3_1 = conv(conv(c2, "conv3", 2, 2), "conv3_1")
+    sd = model == "FlowNetSD"  # flownet_sd.py:14-119: all-3x3 encoder with conv0 at full resolution, interconvN heads
+    if sd:
+        c0 = conv(x, "conv0")
+        c1_1 = conv(conv(c0, "conv1", 2), "conv1_1")
+        c2 = conv(c1_1, "conv2", 2)                                   # the level-2 skip is conv2 (flownet_sd.py:97)
+        c3_1 = conv(conv(conv(c2, "conv2_1"), "conv3", 2), "conv3_1")
+    else:
+        c1 = conv(x, "conv1", 2, 3)
+        c2 = conv(c1, "conv2", 2, 2)
+        c3_1 = conv(conv(c2, "conv3", 2, 2), "conv3_1")
     c4_1 = conv(conv(c3_1, "conv4", 2), "conv4_1")
     c5_1 = conv(conv(c4_1, "conv5", 2), "conv5_1")
     c6_1 = conv(conv(c5_1, "conv6", 2), "conv6_1")
@@ -65,9 +79,11 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
     for lvl, skip in zip((5, 4, 3, 2), (c5_1, c4_1, c3_1, c2)):
         cur = torch.cat([skip, deconv(cur, f"deconv{lvl}"),
                          deconv(preds[lvl + 1], f"upsample_flow{lvl + 1}to{lvl}", act=False)], 1)
-        preds[lvl] = conv(cur, f"predict_flow{lvl}", act=False)
+        head_in = conv(cur, f"interconv{lvl}", act=False) if sd else cur
+        preds[lvl] = conv(head_in, f"predict_flow{lvl}", act=False)
     n = a.shape[0]
-    gt = np.asarray(gt_flow, np.float32) * np.float32(0.05)
+    # labels: FlowNetS 0.05 * gt (flownet_s.py:123), FlowNetSD 20 * gt (flownet_sd.py:122)
+    gt = np.asarray(gt_flow, np.float32) * np.float32(20.0 if sd else 0.05)
     loss = 0.0
     for lvl, wgt in LOSS_WEIGHTS.items():
         p = preds[lvl]

@@ -28,7 +28,7 @@ def device_signs(tr):
             if tr.x2:  # split-fp16 activations live in fp32 containers: (hi, lo) halves per 8-channel group
                 from src import weights as W
                 vals = W.join_f16x2(vals.view(np.float16))
-            out[rec["name"]] = vals[..., c0:c0 + c] > 0
+            out[rec["name"]] = np.sign(vals[..., c0:c0 + c]).astype(np.int8)  # +1 / -1 / 0 (exactly zero: slope 0.55)
     return out
 
 
@@ -37,7 +37,7 @@ def check_kink_elements(signs, pre):
     flips = 0
     for name, sg in signs.items():
         p = pre[name + "/pre/value"]
-        bad = sg != (p > 0)
+        bad = (sg > 0) != (p > 0)
         assert np.abs(p[bad]).max(initial=0.0) < 1e-4, name
         flips += int(bad.sum())
     return flips
@@ -240,3 +240,53 @@ def test_training_cli_pipeline(tmp_path, golden_dir):
     back2 = cli.unpack_weights(tr2)
     assert set(bundle) == set(back2) and all(np.array_equal(bundle[k], back2[k]) for k in back2)
     assert 'model.ckpt-1' in open(tmp_path / "ckpt" / "checkpoint").read()
+    # the same pipeline on FlowNetSD (python -m src.flownet_sd.train)
+    flags.model, flags.checkpoint, flags.ckpt_format, flags.steps = "FlowNetSD", None, "npz", 2
+    tr3 = cli.main(flags)
+    sd = W.load_npz(str(tmp_path / "ckpt" / "flownet_sd-2.npz"))
+    assert set(sd) == set(W.init_weights("FlowNetSD", 7)) and np.isfinite(float(tr3.loss_dev.item()))
+
+
+def test_oracle_torch_forward_equals_numpy_forward_sd():
+    from src import weights as W
+    wts = W.init_weights("FlowNetSD", 5)
+    a, b, gt = data(1, 128, 128, 0)
+    _, _, preds = reft.flownet_s_loss_and_grads(wts, a, b, gt, scope="FlowNetSD", model="FlowNetSD")
+    want = refm.flownet_sd(wts, {"input_a": a, "input_b": b})
+    for k in preds:
+        np.testing.assert_allclose(preds[k], want[k], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_flownet_sd_gradients_match_oracle(dtype):
+    """The trainer on FlowNetSD (flownet_sd.py:14-160: full-resolution 3x3 stem, all-3x3 encoder, linear interconvN
+    before every head, labels 20 * gt): loss and every filter / bias gradient against the float64 oracle."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetSD", 6)
+    a, b, gt = data(2, 128, 128, 2)
+    gt = gt * np.float32(0.002)  # labels are 20 * gt here: keep them at the scale of the untrained predictions
+    tr = FlowNetSTrainer(wts, 2, 128, 128, dtype=dtype, model="FlowNetSD")
+    loss = float(tr.forward_backward(a, b, gt).item())
+    signs, pre = device_signs(tr), {}
+    want_loss, grads, _ = reft.flownet_s_loss_and_grads(wts, a, b, gt, scope="FlowNetSD", signs=signs, act_grads=pre,
+                                                        model="FlowNetSD")
+    assert abs(loss - want_loss) < 2e-5 * abs(want_loss)
+    check_kink_elements(signs, pre)
+    worst = 0.0
+    for rec in tr.eng.layers:
+        name = f"{rec['scope']}/{rec['name']}"
+        got = rec["dw"].cpu().numpy() / np.float32(tr.loss_scale)
+        if rec["kind"] == "upflow":
+            want = grads[name + "/weights"].astype(np.float32).reshape(-1)
+        else:
+            want = packed_grad(rec, grads[name + "/weights"]).reshape(-1)
+        err = np.abs(got - want).max() / (np.abs(want).max() + 1e-12)
+        berr = 0.0
+        if rec.get("b") is not None:
+            gb, wb = rec["db"].cpu().numpy() / np.float32(tr.loss_scale), grads[name + "/biases"]
+            berr = np.abs(gb - wb).max() / (np.abs(wb).max() + 1e-12)
+        print("  %-28s filter %.2e  bias %.2e" % (name, err, berr))
+        worst = max(worst, err, berr)
+    assert worst < 2e-5
