@@ -40,13 +40,25 @@ def save_checkpoint(out_dir, step, weights, fmt="npz", stem="flownet_s"):
     if fmt == "tf":
         from .. import tf_checkpoint
         name = "model.ckpt-%d" % step
-        tf_checkpoint.save_tf_checkpoint(os.path.join(out_dir, name), dict(weights, global_step=np.int64(step)))
+        tf_checkpoint.save_tf_checkpoint(os.path.join(out_dir, name), dict(weights, global_step=np.int64(step)))  # (+ slots)
         with open(os.path.join(out_dir, "checkpoint"), "w") as f:
             f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
         return os.path.join(out_dir, name)
     path = os.path.join(out_dir, "%s-%d.npz" % (stem, step))
     W.save_npz(path, weights)
     return path
+
+
+def load_full_checkpoint(path):
+    """Everything a checkpoint holds, bookkeeping included ({name: array}): weights, Adam slots, global_step."""
+    from .. import tf_checkpoint, weights as W
+    path = str(path)
+    for suffix in (".index", ".data-00000-of-00001", ".meta"):
+        if path.endswith(suffix) and tf_checkpoint.is_tf_checkpoint(path[:-len(suffix)]):
+            path = path[:-len(suffix)]
+    if tf_checkpoint.is_tf_checkpoint(path):
+        return tf_checkpoint.load_tf_checkpoint(path, float_only=False)
+    return W.load_weights(path)
 
 
 def main(flags):
@@ -64,18 +76,27 @@ def main(flags):
     pre = FLYING_CHAIRS_PREPROCESS
     h, w = (pre["crop_height"], pre["crop_width"]) if flags.augment else (flags.height, flags.width)
     tr = FlowNetSTrainer(wts, flags.batch, h, w, schedule=LONG_SCHEDULE, dtype=flags.dtype, model=model)
+    if flags.checkpoint:  # Adam moments + global_step, when the checkpoint carries them (ours and the reference's do)
+        state = load_full_checkpoint(flags.checkpoint)
+        restored = tr.load_optimizer_state(state)
+        if rank == 0 and restored:
+            print("resumed %d optimizer slots at global step %d" % (restored, tr.step_count), flush=True)
     os.makedirs(flags.out, exist_ok=True)
     t0 = time.perf_counter()
-    for step, (a, b, f) in enumerate(load_batches(flags.list, flags.batch, pre, flags.augment, seed=flags.seed + rank), 1):
+    step0 = tr.step_count
+    end = step0 + flags.steps  # --steps counts the steps of THIS run; `step` is the global step (schedule, file names)
+    for step, (a, b, f) in enumerate(load_batches(flags.list, flags.batch, pre, flags.augment, seed=flags.seed + rank,
+                                                  global_step=step0), step0 + 1):
         loss = tr.train_step(a, b, f)
-        if step % flags.log_every == 0 or step == flags.steps:
+        if step % flags.log_every == 0 or step == end:
             val = float(loss.item()) + (tr.l2_term() if flags.report_l2 else 0.0)
             if rank == 0:
                 print("global step %6d | loss %.5f | %.1f pairs/s" % (step, val, world * flags.batch * step /
                                                                       (time.perf_counter() - t0)), flush=True)
-        if rank == 0 and (step % flags.save_every == 0 or step == flags.steps):
-            save_checkpoint(flags.out, step, unpack_weights(tr), flags.ckpt_format, stem=model.lower().replace("net", "net_"))
-        if step >= flags.steps:
+        if rank == 0 and (step % flags.save_every == 0 or step == end):
+            save_checkpoint(flags.out, step, dict(unpack_weights(tr), **tr.optimizer_state()), flags.ckpt_format,
+                            stem=model.lower().replace("net", "net_"))
+        if step >= end:
             break
     return tr
 

@@ -137,10 +137,15 @@ class FlowNetSTrainer:
         self.v_arena = torch.zeros_like(self.grad_arena)
         self.params = []
         off = 0
+        last = None
         for t, reg, rec in params:
             n = t.numel()
             g = self.grad_arena[off:off + n]
-            self.params.append(dict(w=t, g=g, m=self.m_arena[off:off + n], v=self.v_arena[off:off + n], reg=reg, n=n))
+            # rec is None for a bias: it follows its layer's weight in `params`
+            name = f"{rec['scope']}/{rec['name']}/weights" if rec is not None else f"{last['scope']}/{last['name']}/biases"
+            last = rec if rec is not None else last
+            self.params.append(dict(w=t, g=g, m=self.m_arena[off:off + n], v=self.v_arena[off:off + n], reg=reg, n=n,
+                                    name=name, rec=rec))
             if rec is not None:
                 rec["dw"] = g
             off += _round_up(n, 4)
@@ -398,6 +403,52 @@ class FlowNetSTrainer:
                                                 _hip.ptr(self._adam_l2), len(self.params), lr, b1, b2, self.eps,
                                                 self.step_count, 1.0 / (world * self.loss_scale), s))
         self.refresh_backward_weights()
+
+    # ------------------------------------------------------------------ optimizer state (checkpoint resume)
+    def _to_reference_layout(self, p, flat):
+        """A packed fp32 tensor with the geometry of parameter p -> the reference layout of that variable."""
+        rec = p["rec"]
+        a = flat.detach().cpu().numpy().reshape(-1)
+        if rec is None:
+            return a.copy()                       # bias
+        if rec["kind"] == "upflow":
+            return a.reshape(4, 4, 2, 2).copy()
+        return a[_index_hwio(rec)].astype(np.float32)
+
+    def _from_reference_layout(self, p, arr):
+        rec = p["rec"]
+        arr = np.asarray(arr, np.float32)
+        if rec is None or rec["kind"] == "upflow":
+            return arr.reshape(-1)
+        out = np.zeros(p["n"], np.float32)
+        out[_index_hwio(rec).reshape(-1)] = arr.reshape(-1)
+        return out
+
+    def optimizer_state(self):
+        """Adam's moments and counters under TensorFlow's slot names, in the reference layouts: ``<var>/Adam`` (m),
+        ``<var>/Adam_1`` (v), ``beta1_power``, ``beta2_power`` (tf.train.AdamOptimizer, net.py:1290-1295) and
+        ``global_step`` -- what the reference's Saver writes next to the variables, so a resumed run continues the
+        moment estimates and the learning-rate schedule instead of restarting them."""
+        b1, b2 = self.schedule["momentum"], self.schedule["momentum2"]
+        out = {"global_step": np.int64(self.step_count), "beta1_power": np.float32(b1 ** (self.step_count + 1)),
+               "beta2_power": np.float32(b2 ** (self.step_count + 1))}
+        for p in self.params:
+            out[p["name"] + "/Adam"] = self._to_reference_layout(p, p["m"])
+            out[p["name"] + "/Adam_1"] = self._to_reference_layout(p, p["v"])
+        return out
+
+    def load_optimizer_state(self, state):
+        """Restore what optimizer_state() wrote (or a TensorFlow checkpoint of the reference holds).  Returns the
+        number of slot tensors restored; variables without slots keep zero moments."""
+        n = 0
+        for p in self.params:
+            for suffix, dst in (("/Adam", p["m"]), ("/Adam_1", p["v"])):
+                if p["name"] + suffix in state:
+                    dst.copy_(torch.from_numpy(self._from_reference_layout(p, state[p["name"] + suffix])))
+                    n += 1
+        if "global_step" in state:
+            self.step_count = int(np.asarray(state["global_step"]).reshape(-1)[0])
+        return n
 
     def train_step(self, input_a, input_b, gt_flow):
         loss = self.forward_backward(input_a, input_b, gt_flow, reduce=True)
