@@ -30,8 +30,11 @@ __device__ __forceinline__ float wave_sum_t(float v) {
 //   L = weight * sum_{n,y,x} ||pred - label||_2 / N ;  dpred = weight / N * (pred - label) / ||pred - label||
 // (0 where the difference is exactly 0).  loss_accum += L (one atomic per block).
 // ---------------------------------------------------------------------------
+// pixw != nullptr: per-pixel weights of the hard-flow-example-mining losses (utils.py:227-339): the 0 / (1 + lambda) *
+// #pixels / #hard mask of 'hard', or 1 + lambda * edges of 'edges';  L = weight / N * sum w_pix ||pred - label||.
 __global__ void __launch_bounds__(256) epe_loss_grad_kernel(const float* __restrict__ pred,
-                                                            const float* __restrict__ label, float* __restrict__ dpred,
+                                                            const float* __restrict__ label,
+                                                            const float* __restrict__ pixw, float* __restrict__ dpred,
                                                             float* __restrict__ loss_accum, long npix, float scale,
                                                             float grad_mult) {
   float part = 0.f;
@@ -39,9 +42,10 @@ __global__ void __launch_bounds__(256) epe_loss_grad_kernel(const float* __restr
     const float2 p = *reinterpret_cast<const float2*>(pred + 2 * i);
     const float2 l = *reinterpret_cast<const float2*>(label + 2 * i);
     const float du = p.x - l.x, dv = p.y - l.y;
+    const float wp = pixw != nullptr ? pixw[i] : 1.f;
     const float e = sqrtf(du * du + dv * dv);
-    part += e;
-    const float inv = e > 0.f ? scale * grad_mult / e : 0.f;
+    part += wp * e;
+    const float inv = e > 0.f ? wp * scale * grad_mult / e : 0.f;
     *reinterpret_cast<float2*>(dpred + 2 * i) = make_float2(du * inv, dv * inv);
   }
   part = wave_sum_t(part);
@@ -775,8 +779,19 @@ int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float
   FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1, "epe_loss_grad: bad dims");
   const long npix = (long)n * h * w;
   hipLaunchKernelGGL(epe_loss_grad_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, pred, label,
-                     dpred, loss_accum, npix, weight / (float)n, grad_mult);
+                     (const float*)nullptr, dpred, loss_accum, npix, weight / (float)n, grad_mult);
   FN2_CHECK_LAUNCH("epe_loss_grad");
+  return FN2_OK;
+}
+
+int fn2_epe_loss_grad_weighted(const float* pred, const float* label, const float* pixel_weight, float* dpred,
+                               float* loss_accum, int n, int h, int w, float weight, float grad_mult, void* stream) {
+  FN2_REQUIRE(pred && label && pixel_weight && dpred && loss_accum, "epe_loss_grad_weighted: null pointer");
+  FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1, "epe_loss_grad_weighted: bad dims");
+  const long npix = (long)n * h * w;
+  hipLaunchKernelGGL(epe_loss_grad_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, pred, label,
+                     pixel_weight, dpred, loss_accum, npix, weight / (float)n, grad_mult);
+  FN2_CHECK_LAUNCH("epe_loss_grad_weighted");
   return FN2_OK;
 }
 

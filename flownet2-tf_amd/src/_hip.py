@@ -72,6 +72,7 @@ PROTOTYPES = {
     "fn2_stack_input": (_i, [_p, _p, _p, _tp, _i, _p]),
     "fn2_fusion_input": (_i, [_p, _p, _p, _p, _tp, _i, _p]),
     "fn2_epe_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
+    "fn2_epe_loss_grad_weighted": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "fn2_leaky_bwd": (_i, [_tp, _tp, _p, _p]),
     "fn2_bias_grad": (_i, [_tp, _p, _p]),
     "fn2_gather_f32": (_i, [_p, _p, _p, C.c_int64, _p]),

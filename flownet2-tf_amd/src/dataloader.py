@@ -138,3 +138,44 @@ def load_batches(list_path, batch_size, preprocess=FLYING_CHAIRS_PREPROCESS, dat
         if not produced:
             raise ValueError("%s holds fewer than one batch (%d) of samples" % (list_path, batch_size))
         epoch += 1
+
+
+def load_interp_batches(tfrecord_path, batch_size, image_size=(384, 512), seed=0, epochs=None, scale=False,
+                        shuffle_buffer=256):
+    """Batches for FlowNetS_interp from the reference's `image_matches` records (dataloader.py:211-245: image_a and
+    matches_a float64, sparse_flow / edges_a / flow float32, all at the dataset's padded size): device tensors
+    (image_a [B,h,w,3], matches_a [B,h,w,1], sparse_flow [B,h,w,2], edges_a [B,h,w,1], flow [B,h,w,2]).  No
+    augmentation: the reference's `augment_all_interp` (random crops / flips / colour / re-sampling of the sparse
+    flow, dataloader.py:30-80) is not built."""
+    from . import tfrecord
+    names = ("image_a", "matches_a", "sparse_flow", "edges_a", "flow")
+    rng = np.random.default_rng(seed)
+    div = 255.0 if scale else 1.0
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(P._hip.require_device())
+    epoch = 0
+    while epochs is None or epoch < epochs:
+        buf, pick, produced = [], [], False
+
+        def emit(items):
+            return tuple(dev(np.stack([it[i] for it in items]).astype(np.float32)) for i in range(5))
+
+        def samples():
+            for smp in tfrecord.read_samples(tfrecord_path, image_size[0], image_size[1], names):
+                item = (smp["image_a"] / div, smp["matches_a"] / div, smp["sparse_flow"], smp["edges_a"], smp["flow"])
+                if len(buf) < shuffle_buffer:
+                    buf.append(item)
+                    continue
+                k = int(rng.integers(len(buf)))
+                out, buf[k] = buf[k], item
+                yield out
+            for k in rng.permutation(len(buf)):
+                yield buf[k]
+
+        for item in samples():
+            pick.append(item)
+            if len(pick) == batch_size:
+                yield emit(pick)
+                pick, produced = [], True
+        if not produced:
+            raise ValueError("%s holds fewer than one batch (%d) of samples" % (tfrecord_path, batch_size))
+        epoch += 1

@@ -52,7 +52,8 @@ def _index_hwio(rec):
 
 
 class FlowNetSTrainer:
-    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8, dtype="f32", model="FlowNetS"):
+    def __init__(self, weights, batch, height, width, schedule=LONG_SCHEDULE, eps=1e-8, dtype="f32", model="FlowNetS",
+                 add_hard_flow_mining="", lambda_weight=2.0, hard_examples_perc=50):
         """dtype 'f32': everything on the fp32 matrix cores.  'f16x2': activations, activation gradients and the
         weight copies the convolutions read are split fp16 (3 fp16 MFMAs per product, fp32 accumulate); the master
         weights, their gradients and the Adam state stay fp32."""
@@ -65,9 +66,17 @@ class FlowNetSTrainer:
         self.loss_scale = 16384.0 if self.x2 else 1.0
         self.code = _hip.FN2_F16X2 if self.x2 else F32
         self.host_weights = weights
-        if model not in ("FlowNetS", "FlowNetSD"):
-            raise ValueError("the trainer covers the networks without correlation / flow_warp: FlowNetS, FlowNetSD")
+        if model not in ("FlowNetS", "FlowNetSD", "FlowNetS_interp"):
+            raise ValueError("the trainer covers the networks without correlation / flow_warp: FlowNetS, FlowNetSD, "
+                             "FlowNetS_interp")
         self.model = model
+        # hard-flow-example mining of FlowNetS_interp.loss (flownet_s_interp.py:159-254, utils.py:227-339): '' plain
+        # AEPE, 'hard' the top hard_examples_perc % EPE pixels of the batch weighted (1 + lambda), 'edges' every pixel
+        # weighted 1 + lambda * edge map (given per batch)
+        self.hfem = (add_hard_flow_mining or "").lower()
+        if self.hfem not in ("", "hard", "edges"):
+            raise ValueError("add_hard_flow_mining must be '', 'hard' or 'edges'")
+        self.lambda_w, self.hard_perc = float(lambda_weight), float(hard_examples_perc)
         # label scale of the loss: 0.05 * gt for FlowNetS (flownet_s.py:123), 20 * gt for FlowNetSD (flownet_sd.py:122)
         self.gt_scale = 20.0 if model == "FlowNetSD" else 0.05
         self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False)
@@ -119,6 +128,11 @@ class FlowNetSTrainer:
         self.gbufs = {}
         self.gcode = {}  # gradient buffer -> fn2_dtype of the activation buffer it mirrors
         layers = eng.layers
+        for rec in layers:
+            # a bias the checkpoint does not define (FlowNetS_interp's heads, flownet_s_interp.py:86-95) is the engine's
+            # constant zero vector, not a variable: no gradient, no Adam state, not saved
+            if rec.get("b") is not None and f"{rec['scope']}/{rec['name']}/biases" not in self.host_weights:
+                rec["b"] = None
         # ---- parameters and one flat gradient / moment arena (single all-reduce, single memset)
         params = []  # (tensor, l2 flag)
         self.fwd_copies = []  # f16x2 trainer: (split-fp16 forward weight, fp32 master, scale)
@@ -281,8 +295,9 @@ class FlowNetSTrainer:
         gx = self._gbuf(sbuf)
         vx, vg = self._view(sbuf, sc, sc0), self._view(dpf, 2, 0)
         self.keep += [vx, vg]
-        ops = [(self.lib.fn2_head_bwd_filter, (C.byref(vx), _hip.ptr(dpf), _hip.ptr(rec["dw"]), rec["cin_pad"], rec["kpad"])),
-               (self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"])))]
+        ops = [(self.lib.fn2_head_bwd_filter, (C.byref(vx), _hip.ptr(dpf), _hip.ptr(rec["dw"]), rec["cin_pad"], rec["kpad"]))]
+        if rec.get("b") is not None:  # FlowNetS_interp's heads carry no biases (no_deconv_biases, flownet_s_interp.py:86-95)
+            ops.append((self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"]))))
         vdx = self._view(gx, sc, sc0)
         self.keep.append(vdx)
         ops.append((self.lib.fn2_head_bwd_data, (_hip.ptr(dpf), _hip.ptr(rec["master"]), C.byref(vdx), rec["cin_pad"], rec["kpad"])))
@@ -331,7 +346,35 @@ class FlowNetSTrainer:
                 return lr[i]
         return lr[-1]
 
-    def forward_backward(self, input_a, input_b, gt_flow, reduce=False):
+    def forward_backward_interp(self, input_a, matches_a, sparse_flow, gt_flow, edges=None, reduce=False):
+        """FlowNetS_interp: the tower's second 'image' is [0.05 * sparse_flow | matches] (flownet_s_interp.py:34-38)."""
+        dev = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(
+            device=self.dev, dtype=torch.float32)
+        m = dev(matches_a)
+        if m.ndim == 3:
+            m = m[..., None]
+        return self.forward_backward(dev(input_a), torch.cat([dev(sparse_flow) * 0.05, m], dim=3), gt_flow, reduce=reduce,
+                                     edges=edges)
+
+    def _pixel_weights(self, pred, label, edges_dev):
+        """Per-pixel loss weights of the mining modes (None for plain AEPE).  The selection itself (top-k over the
+        batch's EPE map, a few thousand to a few hundred thousand values) is a torch device op; the weighted loss and
+        its gradient stay in the HIP kernel."""
+        if self.hfem == "hard":
+            d = pred - label
+            epe = torch.sqrt((d * d).sum(dim=3)).reshape(-1)
+            k = int(np.round(np.float32(self.hard_perc / 100) * np.float32(epe.numel())))  # tf.round: half to even
+            wgt = torch.zeros_like(epe)
+            if k > 0:
+                wgt[torch.topk(epe, k).indices] = (1.0 + self.lambda_w) * (epe.numel() / k)
+            return wgt
+        if self.hfem == "edges" and edges_dev is not None:
+            from .downsample import downsample
+            e = downsample(edges_dev, [pred.shape[1], pred.shape[2]])
+            return (1.0 + self.lambda_w * e[..., 0]).contiguous().reshape(-1)
+        return None
+
+    def forward_backward(self, input_a, input_b, gt_flow, reduce=False, edges=None):
         """Loss and all parameter gradients (left in self.grad_arena).  Returns the loss as a device scalar.
         reduce=True: every gradient bucket is all-reduced as soon as backward has produced it (overlap);
         finish with apply_gradients(reduced_world=...) / wait_reduction()."""
@@ -345,14 +388,26 @@ class FlowNetSTrainer:
         eng.launch()
         # ---- loss and its gradient at the five scales (flownet_s.py:122-158)
         gts = self.gt * self.gt_scale
+        edges_dev = None
+        if edges is not None:
+            edges_dev = (edges if isinstance(edges, torch.Tensor) else torch.as_tensor(np.asarray(edges))).to(
+                device=self.dev, dtype=torch.float32)
+            if edges_dev.ndim == 3:
+                edges_dev = edges_dev[..., None]
         for lvl, wgt in LOSS_WEIGHTS.items():
             pred = eng.outputs["predict_flow%d" % lvl]
             n, h, w, _ = pred.shape
             label = torch.empty_like(pred)
             _hip.check(self.lib.fn2_downsample_f32(_hip.ptr(gts), _hip.ptr(label), n, self.H, self.W, 2, h, w, s))
-            _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
-                                                  _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, self.loss_scale, s))
-            self.keep_label = label
+            pw = self._pixel_weights(pred, label, edges_dev) if self.hfem else None
+            if pw is None:
+                _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
+                                                      _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, self.loss_scale, s))
+            else:
+                _hip.check(self.lib.fn2_epe_loss_grad_weighted(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(pw),
+                                                               _hip.ptr(self._gbuf(pred)), _hip.ptr(self.loss_dev), n, h, w,
+                                                               wgt / 5.0, self.loss_scale, s))
+            self.keep_label = (label, pw)
         # ---- backward
         from .dist import allreduce_bucket_async
         self._pending, nb = [], 0

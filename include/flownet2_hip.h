@@ -228,6 +228,11 @@ int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const
  * the fp16 exponent range; removed again by fn2_adam_step's grad_scale), 1 otherwise. */
 int fn2_epe_loss_grad(const float* pred, const float* label, float* dpred, float* loss_accum, int n, int h, int w,
                       float weight, float grad_mult, void* stream);
+/* The same with a per-pixel weight [n,h,w] (fp32): the hard-flow-example-mining variants of
+ * average_endpoint_error_hfem (src/utils.py:227-339) -- 'hard': weight = (1 + lambda) * #pixels / #hard on the top-k
+ * EPE pixels of the batch and 0 elsewhere; 'edges': 1 + lambda * edges.  L = weight / n * sum w_pix ||pred - label||. */
+int fn2_epe_loss_grad_weighted(const float* pred, const float* label, const float* pixel_weight, float* dpred,
+                               float* loss_accum, int n, int h, int w, float weight, float grad_mult, void* stream);
 /* g *= LeakyReLU'(.) evaluated from the layer output y (utils.py:401-405); y, g fp32 channel-slice views.
  * db != NULL: the bias gradient of the same layer in the same pass, db[c] += sum over pixels of the new g. */
 int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* stream);

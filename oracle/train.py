@@ -28,7 +28,7 @@ def _leaky(x, positive=None):
 
 
 def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS", l2=0.0, act_grads=None, signs=None,
-                             model="FlowNetS"):
+                             model="FlowNetS", add_hfem="", lambda_w=2.0, perc_hfem=50, edges=None):
     """Returns (loss, {variable name: gradient in the reference layout}, predictions).  l2 > 0 adds the slim
     regulariser 0.5*l2*|W|^2 of the slim.conv2d weights to the loss (and so l2*W to their gradients).
     act_grads: optional dict, filled with {layer name: dLoss/d(layer output), NHWC} for debugging.
@@ -41,7 +41,7 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
 
     def conv(x, name, stride=1, pad=1, act=True):
         w = P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1)
-        y = F.conv2d(x, w, P[f"{scope}/{name}/biases"], stride=stride, padding=pad)
+        y = F.conv2d(x, w, P.get(f"{scope}/{name}/biases"), stride=stride, padding=pad)  # interp heads: no bias
         if act_grads is not None:
             acts[name + "/pre"] = y
         y = _leaky(y, None if signs is None else signs.get(name)) if act else y
@@ -88,7 +88,17 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
     for lvl, wgt in LOSS_WEIGHTS.items():
         p = preds[lvl]
         label = torch.tensor(ops.downsample(gt, (p.shape[2], p.shape[3])).astype(np.float64)).permute(0, 3, 1, 2)
-        loss = loss + wgt * torch.sqrt(((p - label) ** 2).sum(1)).sum() / n
+        epe = torch.sqrt(((p - label) ** 2).sum(1))
+        mode = (add_hfem or "").lower()
+        if mode == "hard":  # utils.py:227-312: the top-k EPE values of the batch, (1 + lambda), rescaled by #pixels / k
+            flat = epe.reshape(-1)
+            k = int(np.round(np.float32(perc_hfem / 100) * np.float32(flat.numel())))
+            loss = loss + wgt * (1.0 + lambda_w) * torch.topk(flat, k).values.sum() / n * (flat.numel() / max(k, 1))
+        elif mode == "edges" and edges is not None:  # utils.py:313-320, edges downsampled per scale (flownet_s_interp.py)
+            e = torch.tensor(ops.downsample(np.asarray(edges, np.float32), (p.shape[2], p.shape[3])).astype(np.float64))[..., 0]
+            loss = loss + wgt * (epe + lambda_w * epe * e).sum() / n
+        else:
+            loss = loss + wgt * epe.sum() / n
     loss = loss / 5.0  # compute_weighted_loss, SUM_BY_NONZERO_WEIGHTS over the five scalars
     if l2 > 0:
         for k, v in P.items():

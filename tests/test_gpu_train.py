@@ -299,3 +299,63 @@ def test_flownet_sd_gradients_match_oracle(dtype):
         print("  %-28s filter %.2e  bias %.2e" % (name, err, berr))
         worst = max(worst, err, berr)
     assert worst < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["", "hard", "edges"])
+def test_flownet_s_interp_gradients_match_oracle(mode):
+    """FlowNetS_interp training (flownet_s_interp.py:21-254): the S tower on [image | 0.05 * sparse flow | matches],
+    heads without biases, multiscale loss with hard-flow-example mining ('hard': top 50 % EPE pixels of the batch,
+    'edges': edge-map weights) -- loss and all gradients against the float64 oracle."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetS_interp", 9)
+    a, _, gt = data(2, 128, 128, 4)
+    rng = np.random.default_rng(5)
+    matches = (rng.random((2, 128, 128, 1)) < 0.05).astype(np.float32)
+    sparse = (gt * matches).astype(np.float32)
+    edges = rng.random((2, 128, 128, 1)).astype(np.float32) if mode == "edges" else None
+    tr = FlowNetSTrainer(wts, 2, 128, 128, dtype="f32", model="FlowNetS_interp", add_hard_flow_mining=mode,
+                         lambda_weight=2.0, hard_examples_perc=50)
+    loss = float(tr.forward_backward_interp(a, matches, sparse, gt, edges=edges).item())
+    b_equiv = np.concatenate([sparse * np.float32(0.05), matches], axis=3)
+    want_loss, grads, _ = reft.flownet_s_loss_and_grads(wts, a, b_equiv, gt, signs=device_signs(tr), add_hfem=mode,
+                                                        lambda_w=2.0, perc_hfem=50, edges=edges)
+    assert abs(loss - want_loss) < 2e-5 * abs(want_loss), (loss, want_loss)
+    worst = 0.0
+    for rec in tr.eng.layers:
+        name = f"{rec['scope']}/{rec['name']}"
+        assert rec.get("b") is None or "predict_flow" not in name  # heads carry no biases
+        got = rec["dw"].cpu().numpy()
+        want = (grads[name + "/weights"].astype(np.float32).reshape(-1) if rec["kind"] == "upflow"
+                else packed_grad(rec, grads[name + "/weights"]).reshape(-1))
+        worst = max(worst, np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+    # 'hard': an EPE value within fp32 rounding of the k-th largest may fall on the other side of the cut than in
+    # float64 (one pixel of a level in or out of the mask)
+    assert worst < (2e-5 if mode != "hard" else 2e-3), worst
+
+
+@pytest.mark.gpu
+def test_interp_training_cli(tmp_path):
+    """python -m src.flownet_s_interp.train end to end: `image_matches` TFRecords -> loader -> trainer with 'hard'
+    mining in split fp16 -> checkpoint (weights without head biases + Adam slots)."""
+    import types
+    from src import tfrecord, weights as W
+    from src.flownet_s_interp import train as cli
+    rng = np.random.default_rng(11)
+    path = str(tmp_path / "interp.tfrecords")
+    with tfrecord.TFRecordWriter(path) as w:
+        for _ in range(4):
+            img = rng.random((128, 192, 3))
+            flow = np.clip(rng.standard_normal((128, 192, 2)) * 3, -20, 20).astype(np.float32)
+            m = (rng.random((128, 192, 1)) < 0.05).astype(np.float64)
+            w.write(tfrecord.encode_sample(img, flow=flow, matches_a=m, sparse_flow=(flow * m).astype(np.float32),
+                                           edges_a=rng.random((128, 192, 1)).astype(np.float32)))
+    flags = types.SimpleNamespace(records=path, out=str(tmp_path / "ck"), checkpoint=None, ckpt_format="npz", steps=2,
+                                  batch=2, dtype="f16x2", height=128, width=192, add_hard_flow_mining="hard",
+                                  lambda_weight=2.0, hard_examples_perc=50, seed=3, log_every=1, save_every=10)
+    tr = cli.main(flags)
+    assert tr.step_count == 2 and np.isfinite(float(tr.loss_dev.item()))
+    saved = W.load_npz(str(tmp_path / "ck" / "flownet_s_interp-2.npz"))
+    assert "FlowNetS/conv1/weights" in saved and "FlowNetS/conv1/weights/Adam_1" in saved
+    assert not any("/predict_flow" in k and k.endswith("/biases") for k in saved)
