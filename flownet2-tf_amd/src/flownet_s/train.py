@@ -13,7 +13,7 @@ import time
 import numpy as np
 
 from ..dataloader import FLYING_CHAIRS_PREPROCESS, load_batches
-from ..training_schedules import LONG_SCHEDULE
+from ..training_schedules import LONG_SCHEDULE, SCHEDULES
 
 
 def unpack_weights(trainer):
@@ -75,7 +75,14 @@ def main(flags):
     wts = W.load_weights(flags.checkpoint) if flags.checkpoint else W.init_weights(model, flags.seed)
     pre = FLYING_CHAIRS_PREPROCESS
     h, w = (pre["crop_height"], pre["crop_width"]) if flags.augment else (flags.height, flags.width)
-    tr = FlowNetSTrainer(wts, flags.batch, h, w, schedule=LONG_SCHEDULE, dtype=flags.dtype, model=model)
+    sched_name = getattr(flags, "training_schedule", "long_schedule").lower()
+    if sched_name not in SCHEDULES:
+        raise ValueError("--training_schedule must be one of: %s" % ", ".join(sorted(SCHEDULES)))
+    tr = FlowNetSTrainer(wts, flags.batch, h, w, schedule=SCHEDULES[sched_name], dtype=flags.dtype, model=model)
+    # parameters of the computed policies (clr / one_cycle / exp_decr / lr_range_test; net.py:1139-1190)
+    tr.train_params = {k: getattr(flags, k) for k in ("clr_min_lr", "clr_max_lr", "clr_stepsize", "clr_gamma", "clr_mode",
+                                                      "one_cycle_annealing_factor", "start_lr", "end_lr")
+                       if getattr(flags, k, None) is not None}
     if flags.checkpoint:  # Adam moments + global_step, when the checkpoint carries them (ours and the reference's do)
         state = load_full_checkpoint(flags.checkpoint)
         restored = tr.load_optimizer_state(state)
@@ -119,6 +126,12 @@ def parse_and_run(model):
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--save-every", type=int, default=1000)
     ap.add_argument("--report-l2", action="store_true", help="add the L2 regulariser to the printed loss")
+    ap.add_argument("--training_schedule", default="long_schedule",
+                    help="long_schedule (default), fine_schedule, short_schedule, finetune_sintel_s1..5, finetune_kitti_s1..4, "
+                         "finetune_rob, clr, one_cycle, exp_decr, lr_range_test (src/training_schedules.py)")
+    for name, typ in (("clr_min_lr", float), ("clr_max_lr", float), ("clr_stepsize", int), ("clr_gamma", float),
+                      ("clr_mode", str), ("one_cycle_annealing_factor", float), ("start_lr", float), ("end_lr", float)):
+        ap.add_argument("--" + name, type=typ, default=None)
     FLAGS = ap.parse_args()
     FLAGS.model = model
     if not os.path.exists(FLAGS.list):

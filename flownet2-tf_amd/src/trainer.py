@@ -340,11 +340,10 @@ class FlowNetSTrainer:
             _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wx2), _hip.ptr(master), None, master.numel(), scale, s))
 
     def learning_rate(self, step):
-        lr = self.schedule["learning_rates"]
-        for i, b in enumerate(self.schedule["step_values"]):
-            if step < b:
-                return lr[i]
-        return lr[-1]
+        """Piecewise-constant schedules and the computed policies (CLR, one-cycle, exponential, LR range test):
+        src/training_schedules.py; policy parameters in self.train_params (clr_min_lr, clr_max_lr, clr_stepsize, ...)."""
+        from .training_schedules import learning_rate
+        return learning_rate(self.schedule, step, getattr(self, "train_params", None))
 
     def forward_backward_interp(self, input_a, matches_a, sparse_flow, gt_flow, edges=None, reduce=False):
         """FlowNetS_interp: the tower's second 'image' is [0.05 * sparse_flow | matches] (flownet_s_interp.py:34-38)."""
