@@ -100,6 +100,12 @@ def main(flags):
             if rank == 0:
                 print("global step %6d | loss %.5f | %.1f pairs/s" % (step, val, world * flags.batch * step /
                                                                       (time.perf_counter() - t0)), flush=True)
+        val_every = getattr(flags, "val_every", 0)
+        if rank == 0 and getattr(flags, "val_list", None) and val_every and (step % val_every == 0 or step == end):
+            vb = load_batches(flags.val_list, flags.batch, pre, False, seed=0, epochs=1,
+                              image_size=(flags.height, flags.width))
+            print("global step %6d | validation EPE %.4f px" % (step, tr.evaluate(vb, getattr(flags, "val_batches", None))),
+                  flush=True)
         if rank == 0 and (step % flags.save_every == 0 or step == end):
             save_checkpoint(flags.out, step, dict(unpack_weights(tr), **tr.optimizer_state()), flags.ckpt_format,
                             stem=model.lower().replace("net", "net_"))
@@ -126,6 +132,9 @@ def parse_and_run(model):
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--save-every", type=int, default=1000)
     ap.add_argument("--report-l2", action="store_true", help="add the L2 regulariser to the printed loss")
+    ap.add_argument("--val-list", dest="val_list", default=None, help="validation list file or .tfrecords (no augmentation)")
+    ap.add_argument("--val-every", dest="val_every", type=int, default=0, help="validate every N steps (0 = never)")
+    ap.add_argument("--val-batches", dest="val_batches", type=int, default=None, help="at most this many validation batches")
     ap.add_argument("--training_schedule", default="long_schedule",
                     help="long_schedule (default), fine_schedule, short_schedule, finetune_sintel_s1..5, finetune_kitti_s1..4, "
                          "finetune_rob, clr, one_cycle, exp_decr, lr_range_test (src/training_schedules.py)")

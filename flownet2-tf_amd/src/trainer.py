@@ -458,6 +458,25 @@ class FlowNetSTrainer:
                                                 self.step_count, 1.0 / (world * self.loss_scale), s))
         self.refresh_backward_weights()
 
+    # ------------------------------------------------------------------ validation
+    def evaluate(self, batches, max_batches=None):
+        """Forward-only pass over an iterable of (image_a, image_b, gt_flow) device batches with the CURRENT weights:
+        mean endpoint error of the full-resolution `flow` output against the ground truth, in pixels -- the validation
+        the reference interleaves with training (Net.train's custom train_step_fn, net.py:1300-1380: every
+        `valid_iters` steps, average EPE over the validation batches)."""
+        total, count = 0.0, 0
+        for i, (a, b, gt) in enumerate(batches):
+            if max_batches is not None and i >= max_batches:
+                break
+            self.eng.set_inputs(a, b)
+            self.eng.launch()
+            gt_dev = (gt if isinstance(gt, torch.Tensor) else torch.as_tensor(np.asarray(gt))).to(
+                device=self.dev, dtype=torch.float32)
+            d = self.eng.outputs["flow"] - gt_dev
+            total += float(torch.sqrt((d * d).sum(dim=3)).mean().item())
+            count += 1
+        return total / max(count, 1)
+
     # ------------------------------------------------------------------ optimizer state (checkpoint resume)
     def _to_reference_layout(self, p, flat):
         """A packed fp32 tensor with the geometry of parameter p -> the reference layout of that variable."""

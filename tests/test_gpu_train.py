@@ -236,10 +236,13 @@ def test_training_cli_pipeline(tmp_path, golden_dir):
     aa, _, fa = next(load_batches(rec, 2, FLYING_CHAIRS_PREPROCESS, True, seed=3))
     assert aa.shape == (2, 384, 448, 3) and fa.shape == (2, 384, 448, 2)
     flags.list = rec
+    flags.val_list, flags.val_every, flags.val_batches = str(lst), 1, 1   # validation pass inside the loop
     flags.ckpt_format = "tf"  # ... and leave a TensorFlow bundle (model.ckpt-1 + `checkpoint`) like the slim Saver
     tr2 = cli.main(flags)
     assert np.isfinite(float(tr2.loss_dev.item()))
     assert tr2.step_count == 4                               # resumed at global step 3 with the saved moments, ran one
+    epe = tr2.evaluate(load_batches(str(lst), 2, FLYING_CHAIRS_PREPROCESS, False, seed=0, epochs=1))
+    assert np.isfinite(epe) and epe > 0                      # forward-only validation EPE of the current weights
     bundle = W.load_weights(str(tmp_path / "ckpt" / "model.ckpt-4"))
     back2 = cli.unpack_weights(tr2)
     assert set(back2) <= set(bundle) and all(np.array_equal(bundle[k], back2[k]) for k in back2)
