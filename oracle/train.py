@@ -1,8 +1,10 @@
-"""Oracle (test infrastructure): FlowNetS loss gradients and the Adam update on CPU.
+"""Oracle (test infrastructure): FlowNetS / FlowNetSD / FlowNetS_interp loss gradients and the Adam update on CPU.
 
 The gradient of the reference's loss graph (what tf.gradients produces) is obtained by running the same
-graph in torch float64 on the CPU and using autograd; the graph is the one restated in oracle/models.py
-(flownet_s.py:14-161) and tests check this torch forward against that NumPy forward on the same weights.
+graph in torch float64 on the CPU and using autograd; the graphs are the ones restated in oracle/models.py
+(flownet_s.py:14-161, flownet_sd.py:14-160; FlowNetS_interp = the S tower on [image | 0.05 sparse flow | matches]
+without head biases, flownet_s_interp.py:21-157, with the hard-flow-example-mining losses of utils.py:227-339) and
+tests check this torch forward against that NumPy forward on the same weights.
 PARITY UNPINNED like oracle/nn.py (TensorFlow is not available).  The Adam update restates
 tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v moments; w -= lr_t*m/(sqrt(v)+eps).
 """
