@@ -34,10 +34,14 @@ class _Stream:
 
     def __init__(self, f, chunk=1 << 20):
         self.f, self.chunk, self.buf, self.eof = f, chunk, bytearray(), False
-        head = f.read(2)
+        head = f.read(12)
         f.seek(0)
         self.z = None
-        if len(head) == 2 and ((head[0] == 0x78 and (head[0] * 256 + head[1]) % 31 == 0) or head == b"\x1f\x8b"):
+        # an uncompressed file starts with a record header whose length CRC checks out (a 376-byte first record starts
+        # with the bytes 78 01, a valid zlib header: the CRC decides, not the magic); otherwise zlib / gzip by header
+        plain = len(head) == 12 and unmask_crc(struct.unpack("<I", head[8:])[0]) == _crc_bulk(head[:8])
+        if not plain and len(head) >= 2 and ((head[0] == 0x78 and (head[0] * 256 + head[1]) % 31 == 0) or
+                                              head[:2] == b"\x1f\x8b"):
             self.z = zlib.decompressobj(47)  # zlib or gzip header, auto-detected
 
     def _fill(self, n):

@@ -96,3 +96,13 @@ def test_reference_sample_round_trip(tmp_path):
     assert len(got) == 6
     sums = sorted(round(float(g[2].sum()), 1) for g in got)
     assert sums == sorted(round(float(s["flow"].sum()), 1) for s in smps)
+
+
+def test_uncompressed_file_whose_first_length_looks_like_a_zlib_header(tmp_path):
+    path = str(tmp_path / "u.tfrecords")
+    payload = bytes(range(256)) + bytes(120)        # 376 bytes: the length field starts with 78 01, a valid zlib header
+    assert struct.pack("<Q", len(payload))[:2] == b"\x78\x01"
+    with R.TFRecordWriter(path, "") as w:
+        w.write(payload)
+        w.write(b"second")
+    assert list(R.read_records(path)) == [payload, b"second"]
