@@ -31,7 +31,15 @@ F32 = _hip.FN2_F32
 
 def _index_hwio(rec):
     """Flat position inside the layer's packed master weight of every element of its reference-layout
-    weight (HWIO for conv, HW-O-I for deconv): pack an enumeration with the same packer and invert it."""
+    weight (HWIO for conv, HW-O-I for deconv): pack an enumeration with the same packer and invert it.
+    Cached on the layer record (checkpointing asks for it three times per layer: weight, m, v)."""
+    if "_hwio_index" in rec:
+        return rec["_hwio_index"]
+    rec["_hwio_index"] = _index_hwio_uncached(rec)
+    return rec["_hwio_index"]
+
+
+def _index_hwio_uncached(rec):
     kind = rec["kind"]
     if kind == 1:
         shape = (4, 4, rec["cout"], rec["cin"])
