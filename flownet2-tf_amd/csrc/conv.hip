@@ -495,23 +495,25 @@ __global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------
-// upsample_flowXtoY: 2 -> 2 channel transposed conv 4x4 s2 crop 1, linear (flownet_s.py:60-63).
-// HBM-bound: one lane per output pixel.
+// upsample_flowXtoY: 2 -> 2 channel transposed conv 4x4 s2 crop 1, linear (flownet_s.py:60-63; bias only in
+// the FlowNet2 fusion net, flownet2.py:70-73, :86-89).  HBM-bound: one lane per output pixel.
 // ---------------------------------------------------------------------------
 template <typename OutT>
 __global__ void __launch_bounds__(256) upsample_flow_kernel(const float* __restrict__ in,
-                                                            const float* __restrict__ w, OutT* __restrict__ out,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            OutT* __restrict__ out,
                                                             int N, int H, int W, int out_cs, int out_c0) {
   __shared__ float sw[64];
   if (threadIdx.x < 64) sw[threadIdx.x] = w[threadIdx.x];  // [ky][kx][o][i]
   __syncthreads();
+  const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
   const long total = (long)N * 4 * H * W;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(o % (2 * W));
     const int oy = (int)((o / (2 * W)) % (2 * H));
     const int n = (int)(o / (2 * W) / (2 * H));
     const int a = oy & 1, b = ox & 1, y = oy >> 1, x = ox >> 1;
-    float r0 = 0.f, r1 = 0.f;
+    float r0 = b0, r1 = b1;
 #pragma unroll
     for (int ty = 0; ty < 2; ++ty) {
       const int iy = y - 1 + a + ty, ky = 3 - a - 2 * ty;
@@ -742,7 +744,8 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     a.deconv = 0; a.ph_pad0 = a.ph_pad1 = 0;
   } else if (d->kind == 1) {
     FN2_REQUIRE(d->kh == 4 && d->kw == 4 && d->stride == 2, "deconv: only k=4 s=2 crop 1 (flownet_s.py:53-63)");
-    FN2_REQUIRE(d->bias == nullptr, "deconv: the reference transposed convs have no bias (biases_initializer=None)");
+    // bias: nullptr inside the refinement scopes (biases_initializer=None, flownet_s.py:53); the FlowNet2 fusion
+    // net's fuse_deconv1 / fuse_deconv0 carry one (flownet2.py:50-57 opens no such scope, :66-84)
     a.KH = 2; a.KW = 2; a.stride = 1; a.pad = 0;
     a.OH = d->in.h; a.OW = d->in.w;
     FN2_REQUIRE(d->out.h == 2 * d->in.h && d->out.w == 2 * d->in.w, "deconv: output must be 2H x 2W");
@@ -920,7 +923,7 @@ int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out
   return FN2_OK;
 }
 
-int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, int n, int h, int wd,
+int fn2_upsample_flow(const float* in, const float* w, const float* bias, const fn2_tensor* out, int n, int h, int wd,
                       void* stream) {
   FN2_REQUIRE(in && w, "upsample_flow: null pointer");
   int rc = check_view(out, "upsample_flow output");
@@ -930,16 +933,16 @@ int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, in
   const long total = (long)n * 4 * h * wd;
   if (out->dtype == FN2_F32)
     hipLaunchKernelGGL(upsample_flow_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       in, w, (float*)out->data, n, h, wd, out->cs, out->c0);
+                       in, w, bias, (float*)out->data, n, h, wd, out->cs, out->c0);
   else if (out->dtype == FN2_F16X2)
     hipLaunchKernelGGL(upsample_flow_kernel<x2_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       in, w, (x2_t*)out->data, n, h, wd, out->cs, out->c0);
+                       in, w, bias, (x2_t*)out->data, n, h, wd, out->cs, out->c0);
   else if (out->dtype == FN2_BF16)
     hipLaunchKernelGGL(upsample_flow_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       in, w, (bf16_t*)out->data, n, h, wd, out->cs, out->c0);
+                       in, w, bias, (bf16_t*)out->data, n, h, wd, out->cs, out->c0);
   else
     hipLaunchKernelGGL(upsample_flow_kernel<f16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       in, w, (f16_t*)out->data, n, h, wd, out->cs, out->c0);
+                       in, w, bias, (f16_t*)out->data, n, h, wd, out->cs, out->c0);
   FN2_CHECK_LAUNCH("upsample_flow");
   return FN2_OK;
 }

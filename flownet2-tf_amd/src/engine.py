@@ -55,7 +55,12 @@ def _round_up(x, m):
 
 
 class Engine:
-    def __init__(self, model, weights, batch, height, width, dtype="f32", device=None, heads_as_gemm=True):
+    def __init__(self, model, weights, batch, height, width, dtype="f32", device=None, heads_as_gemm=True,
+                 no_deconv_biases=None, strict=True):
+        """no_deconv_biases: FlowNetS_interp's constructor flag (flownet_s_interp.py:12-14); None = what the weights say
+        (no ``FlowNetS/predict_flow6/biases`` entry -> True).  strict: a variable under the model's scopes that no
+        layer consumes raises ValueError (optimizer slots and biases the reference graph does not declare excepted:
+        its Saver restores graph variables only, so those are ignored -- with a warning -- as the reference ignores them)."""
         if model not in netdefs.MODELS:
             raise ValueError("unknown model %r" % model)
         if dtype not in _DT:
@@ -69,6 +74,11 @@ class Engine:
         self.act_code = _CODE[dtype]
         self.code_of = {}  # data_ptr -> fn2_dtype of a buffer
         self.weights = weights
+        if no_deconv_biases is None:
+            no_deconv_biases = "FlowNetS/predict_flow6/biases" not in weights
+        self.no_deconv_biases = bool(no_deconv_biases)
+        self.consumed = set()           # variable names read by some layer
+        self.ignored_variables = []     # biases present in `weights` that the reference graph does not declare
         self.ops = []      # (name, fn, args) ; args exclude the trailing stream
         self.kernel_of = []  # per op: the device kernel (template instantiation) that does the work
         self.keep = []     # keep ctypes structs / tensors alive
@@ -84,6 +94,7 @@ class Engine:
         self.heads_as_gemm = heads_as_gemm
         self._head_t = None
         self.outputs = self._build()
+        self._check_variables(strict)
         self._alloc_workspace()
 
     # ------------------------------------------------------------------ buffers / views
@@ -111,10 +122,47 @@ class Engine:
     def _v(self, buf, c=None, c0=0):
         return _hip.view(buf, c, c0, self._code(buf))
 
-    def _bias(self, scope, name, cout):
-        """Bias vector of a conv layer; a layer declared without one (biases_initializer=None) gets zeros."""
-        b = self.weights.get(f"{scope}/{name}/biases")
-        return W.to_device(b if b is not None else np.zeros(cout, np.float32), torch.float32, self.device)
+    def _w(self, key):
+        """A variable of the checkpoint, marked as consumed."""
+        if key not in self.weights:
+            raise KeyError("the weights lack %r, a variable of the reference's %s graph" % (key, self.model))
+        self.consumed.add(key)
+        return self.weights[key]
+
+    def _bias(self, scope, name, kind, cout):
+        """Bias vector of a layer, or None where the reference graph declares none (netdefs.has_bias: the
+        biases_initializer=None scopes of flownet_s.py:53 / flownet_c.py:58 / flownet_sd.py:44 -- but NOT the FlowNet2
+        fusion net, flownet2.py:50-89 -- and FlowNetS_interp's no_deconv_biases)."""
+        key = f"{scope}/{name}/biases"
+        if not netdefs.has_bias(self.model, name, kind, self.no_deconv_biases):
+            if key in self.weights:
+                self.ignored_variables.append(key)
+            return None
+        b = np.asarray(self._w(key), np.float32).reshape(-1)
+        if b.shape[0] != cout:
+            raise ValueError("%s has %d entries, the layer has %d outputs" % (key, b.shape[0], cout))
+        return W.to_device(b, torch.float32, self.device)
+
+    _SLOT_SUFFIXES = ("/Adam", "/Adam_1", "/Momentum", "/ExponentialMovingAverage")
+
+    def _check_variables(self, strict):
+        """Every variable under the model's scopes must have been read by a layer (a silently dropped tensor is how the
+        FlowNet2 fusion biases went missing in round 1).  Tolerated: optimizer slots / counters, and biases the
+        reference graph does not declare (Caffe's deconvolution biases in a converted .npy: the reference's Saver
+        restores graph variables only) -- those are listed in self.ignored_variables and warned about."""
+        roots = tuple(sorted({scope.split("/")[0] + "/" for scope, _ in netdefs.model_scopes(self.model)}))
+        stray = [k for k in self.weights
+                 if k.startswith(roots) and k not in self.consumed and k not in self.ignored_variables
+                 and not k.endswith(self._SLOT_SUFFIXES)]
+        if self.ignored_variables:
+            import warnings
+            warnings.warn("%s: %d bias tensors of the checkpoint belong to layers the reference graph builds without "
+                          "biases and are ignored, as the reference ignores them (first: %s)"
+                          % (self.model, len(self.ignored_variables), self.ignored_variables[0]))
+        if stray and strict:
+            raise ValueError("%s: %d checkpoint variables are read by no layer (first: %s); pass strict=False to "
+                             "ignore them" % (self.model, len(stray), ", ".join(sorted(stray)[:4])))
+        self.stray_variables = stray
 
     def _op(self, name, fn, *args, kernel=None):
         self.kernel_of.append(kernel if kernel is not None else fn.__name__.replace("fn2_", ""))
@@ -145,11 +193,10 @@ class Engine:
         plan = _hip.conv_plan(in_code, cin_pad, cout)
         tile, layout = plan.cout_tile, plan.layout
         if kind == "conv":
-            packed, cin_pad, cout_pad, kpad = W.pack_conv(self.weights[wname], tile, plan.kstep_elems, cin_pad, layout)
-            bias = self._bias(scope, name, cout)
+            packed, cin_pad, cout_pad, kpad = W.pack_conv(self._w(wname), tile, plan.kstep_elems, cin_pad, layout)
         else:
-            packed, cin_pad, cout_pad, kpad = W.pack_deconv(self.weights[wname], tile, plan.kstep_elems, cin_pad, layout)
-            bias = None
+            packed, cin_pad, cout_pad, kpad = W.pack_deconv(self._w(wname), tile, plan.kstep_elems, cin_pad, layout)
+        bias = self._bias(scope, name, kind, cout)  # transposed convs: only where the graph declares one (fusion net)
         out_scale = 1.0
         if plan.wgt_dtype == _hip.FN2_F16X2:
             # split fp16: scale the weights by 2^k so that max|w| ~ 1024 (lo parts stay normal fp16 numbers
@@ -207,7 +254,7 @@ class Engine:
         plan = _hip.conv_plan(in_code, cin_line, 18)
         if plan.layout != 1:
             return False
-        w = np.asarray(self.weights[f"{scope}/{name}/weights"], np.float32)          # [3,3,cin,2] HWIO
+        w = np.asarray(self._w(f"{scope}/{name}/weights"), np.float32)          # [3,3,cin,2] HWIO
         w1 = np.ascontiguousarray(w.transpose(2, 0, 1, 3)).reshape(1, 1, cin, 18)     # [ci][(ky*3+kx)*2+co]
         packed, cin_pad, cout_pad, kpad = W.pack_conv(w1, plan.cout_tile, plan.kstep_elems, cin_line, plan.layout)
         out_scale = 1.0
@@ -217,7 +264,7 @@ class Engine:
                 k2 = int(math.floor(math.log2(1024.0 / wmax)))
                 packed, out_scale = packed * (2.0 ** k2), 2.0 ** (-k2)
         wdev = W.packed_to_device(packed, plan.wgt_dtype, self.device)
-        bias = self._bias(scope, name, cout)
+        bias = self._bias(scope, name, kind, cout)
         if self._head_t is None:  # one scratch for every head: launches are ordered on one stream
             self._head_t = torch.zeros((self.N * self.H * self.W, 32), dtype=torch.float32, device=self.device)
         n, h, wd = pf.shape[0], pf.shape[1], pf.shape[2]
@@ -234,8 +281,8 @@ class Engine:
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
                  kernel=f"conv_igemm2_kernel<{tn}, float, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1)}>")
-        self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(self._head_t), 32, _hip.ptr(bias),
-                 _hip.ptr(pf), n, h, wd)
+        self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(self._head_t), 32,
+                 _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd)
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
         return True
 
@@ -248,7 +295,7 @@ class Engine:
         dbuf, dc0, dc = dst
         assert kind == "conv" and dc == cout
         k_alg, cin_alg = k, cin
-        w_hwio = self.weights[f"{scope}/{name}/weights"]
+        w_hwio = self._w(f"{scope}/{name}/weights")
         if s2d:
             assert stride == 2 and cin == 3 and sbuf.shape[3] == 16
             k2 = (k + 1) // 2
@@ -264,7 +311,7 @@ class Engine:
         plan = _hip.conv_plan(in_code, run, cout)
         assert plan.layout == 1, (scope, name)
         packed, cin_pad, cout_pad, kpad = W.pack_stem(w_hwio, cs, run, plan.cout_tile, plan.layout)
-        bias = self._bias(scope, name, cout)
+        bias = self._bias(scope, name, kind, cout)
         out_scale = 1.0
         if plan.wgt_dtype == _hip.FN2_F16X2:
             k2 = int(math.floor(math.log2(1024.0 / float(abs(packed).max()))))
@@ -274,7 +321,7 @@ class Engine:
         d.inp = self._v(sbuf, cs, 0)
         d.out = self._v(dbuf, dc, dc0)
         d.wgt = wdev.data_ptr()
-        d.bias = bias.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
         d.kind = 2
         d.kh = d.kw = k
         d.stride, d.pad = stride, 0
@@ -296,12 +343,14 @@ class Engine:
 
     def _upflow(self, scope, name, src_f32, dst):
         dbuf, dc0, dc = dst
-        w = W.to_device(self.weights[f"{scope}/{name}/weights"], torch.float32, self.device)  # [4,4,2,2] HW-O-I
+        w = W.to_device(self._w(f"{scope}/{name}/weights"), torch.float32, self.device)  # [4,4,2,2] HW-O-I
+        b = self._bias(scope, name, "deconv", 2)  # only the fusion net's two (flownet2.py:70-73, :86-89)
         v = self._v(dbuf, dc, dc0)
-        self.keep += [w, v]
+        self.keep += [w, v, b]
         n, h, wd, _ = src_f32.shape
-        self.layers.append(dict(scope=scope, name=name, kind="upflow", src=src_f32, dst=dst, w=w, b=None, view=v))
-        self._op(f"{scope}/{name}", self.lib.fn2_upsample_flow, _hip.ptr(src_f32), _hip.ptr(w), C.byref(v), n, h, wd)
+        self.layers.append(dict(scope=scope, name=name, kind="upflow", src=src_f32, dst=dst, w=w, b=b, view=v))
+        self._op(f"{scope}/{name}", self.lib.fn2_upsample_flow, _hip.ptr(src_f32), _hip.ptr(w),
+                 _hip.ptr(b) if b is not None else None, C.byref(v), n, h, wd)
 
     def _resize(self, name, src_f32, scale):
         n, h, w, c = src_f32.shape

@@ -13,6 +13,6 @@ class FlowNet2(Net):
 
     def loss(self, flow, predictions):
         if self.model_name == 'FlowNet2':
-            return fusion_loss(flow, predictions)
+            return fusion_loss(flow, predictions, self.weights, 'FlowNet2')
         return multiscale_loss(flow, predictions, self.weights, self.model_name,
                                gt_scale=20.0 if self.model_name == 'FlowNetSD' else 0.05)

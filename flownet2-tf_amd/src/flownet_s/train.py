@@ -98,17 +98,26 @@ def main(flags):
         if step % flags.log_every == 0 or step == end:
             val = float(loss.item()) + (tr.l2_term() if flags.report_l2 else 0.0)
             if rank == 0:
-                print("global step %6d | loss %.5f | %.1f pairs/s" % (step, val, world * flags.batch * step /
+                # rate of THIS run: steps since the resumed global step, not the global step
+                print("global step %6d | loss %.5f | %.1f pairs/s" % (step, val, world * flags.batch * (step - step0) /
                                                                       (time.perf_counter() - t0)), flush=True)
         val_every = getattr(flags, "val_every", 0)
-        if rank == 0 and getattr(flags, "val_list", None) and val_every and (step % val_every == 0 or step == end):
+        validate = bool(getattr(flags, "val_list", None) and val_every and (step % val_every == 0 or step == end))
+        save = step % flags.save_every == 0 or step == end
+        if rank == 0 and validate:
+            # validation frames come at their own size (--height/--width or the list's); the trainer's engine is built
+            # at the training size (the augmentation crop when --augment): evaluate() centre-crops larger frames to it
             vb = load_batches(flags.val_list, flags.batch, pre, False, seed=0, epochs=1,
                               image_size=(flags.height, flags.width))
             print("global step %6d | validation EPE %.4f px" % (step, tr.evaluate(vb, getattr(flags, "val_batches", None))),
                   flush=True)
-        if rank == 0 and (step % flags.save_every == 0 or step == end):
+        if rank == 0 and save:
             save_checkpoint(flags.out, step, dict(unpack_weights(tr), **tr.optimizer_state()), flags.ckpt_format,
                             stem=model.lower().replace("net", "net_"))
+        if world > 1 and (validate or save):
+            # rank 0 alone validates / writes: the others wait here instead of inside the next step's first bucket
+            # all-reduce (whose timeout a long validation would hit); every rank takes this branch at the same steps
+            torch.distributed.barrier()
         if step >= end:
             break
     return tr

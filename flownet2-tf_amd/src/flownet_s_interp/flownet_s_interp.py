@@ -4,6 +4,7 @@ of a set of matches (scaled by 0.05) and the match mask -- flow interpolation in
 Variable scope stays 'FlowNetS' (:23), so FlowNetS checkpoints load; with no_deconv_biases (the class default)
 the predict_flow layers carry no biases (:86-95).  The graph runs on the HIP engine (src/engine.py)."""
 from ..net import Net, Mode
+from .. import weights as W
 from ..losses import multiscale_hfem_loss
 
 
@@ -15,12 +16,14 @@ class FlowNetS_interp(Net):
         super(FlowNetS_interp, self).__init__(mode=mode, debug=debug, dtype=dtype)
         self.no_deconv_biases = no_deconv_biases
 
-    def load_weights(self, checkpoint=None, seed=1234):
-        w = super(FlowNetS_interp, self).load_weights(checkpoint, seed)
-        if self.no_deconv_biases:  # a FlowNetS checkpoint may carry head biases: this variant ignores them
-            for k in [k for k in w if "/predict_flow" in k and k.endswith("/biases")]:
-                del w[k]
-        return w
+    def _init_weights(self, seed):
+        return W.init_weights(self.model_name, seed, head_biases=not self.no_deconv_biases)
+
+    # A plain FlowNetS checkpoint carries head biases: with no_deconv_biases they are not variables of this graph
+    # and the engine ignores them (Engine.ignored_variables), as the reference's Saver would.
+
+    def _engine_kwargs(self):
+        return {"no_deconv_biases": self.no_deconv_biases}
 
     def model(self, inputs, training_schedule=None, trainable=True, is_training=True):
         """inputs: {'input_a' [N,H,W,3], 'matches_a' [N,H,W,1], 'sparse_flow' [N,H,W,2]}; is_training=False returns

@@ -26,7 +26,7 @@ def main(flags):
         dist.init_process_group(os.environ.get("FN2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     wts = W.load_weights(flags.checkpoint) if flags.checkpoint else W.init_weights("FlowNetS_interp", flags.seed)
     for k in [k for k in wts if "/predict_flow" in k and k.endswith("/biases")]:
-        del wts[k]  # no_deconv_biases (flownet_s_interp.py:86-95): a FlowNetS checkpoint's head biases are dropped
+        del wts[k]  # no_deconv_biases (flownet_s_interp.py:78-95): a FlowNetS checkpoint's head biases are no variables here
     tr = FlowNetSTrainer(wts, flags.batch, flags.height, flags.width, schedule=LONG_SCHEDULE, dtype=flags.dtype,
                          model="FlowNetS_interp", add_hard_flow_mining=flags.add_hard_flow_mining,
                          lambda_weight=flags.lambda_weight, hard_examples_perc=flags.hard_examples_perc)

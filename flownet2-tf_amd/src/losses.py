@@ -86,7 +86,20 @@ def multiscale_loss(flow, predictions, weights=None, scope=None, l2=4e-4, gt_sca
     return total
 
 
-def fusion_loss(flow, predictions):
+def fusion_loss(flow, predictions, weights=None, scope="FlowNet2", l2=4e-4):
+    """FlowNet2.loss (src/flownet2/flownet2.py:107-116): average_endpoint_error(downsample(flow, size of
+    predict_flow0), predict_flow0) -- the ground truth is NOT scaled and no 0.005 weight is applied, whatever the
+    comment at :108 says -- added to the losses collection, then tf.losses.get_total_loss(): + every
+    regularisation loss of the graph, i.e. 0.5 * l2 * |W|^2 of ALL slim.conv2d weights under the FlowNet2 scope,
+    the frozen CSS / SD sub-networks included (regularisers are attached whether or not a variable is trainable;
+    conv2d_transpose weights and biases carry none).  l2: the schedule's l2_regularization (the reference reads a
+    'weight_decay' key no schedule defines for the fusion layers -- defect D2 -- the intended value is the same)."""
     p0 = predictions['predict_flow0']
     flow = _as_dev(flow, p0).to(device=p0.device, dtype=torch.float32)
-    return average_endpoint_error(downsample(flow, [p0.shape[1], p0.shape[2]]), p0)
+    total = average_endpoint_error(downsample(flow, [p0.shape[1], p0.shape[2]]), p0)
+    if weights is not None:
+        total = total + sum(0.5 * l2 * float(np.sum(np.square(np.asarray(w, np.float64))))
+                            for name, w in weights.items()
+                            if name.startswith(scope + "/") and name.endswith("/weights")
+                            and "deconv" not in name and "upsample_flow" not in name)
+    return total

@@ -59,17 +59,24 @@ class Net(object):
             if checkpoint is not None:
                 sys.stderr.write("WARNING: checkpoint %r not found (TF bundle prefix, .npz or .npy); using seeded synthetic "
                                  "weights (seed %d) -- flows are NOT meaningful predictions\n" % (checkpoint, seed))
-            self.weights = W.init_weights(self.model_name, seed)
+            self.weights = self._init_weights(seed)
         self._engines = {}
         return self.weights
+
+    def _init_weights(self, seed):
+        return W.init_weights(self.model_name, seed)
 
     def engine(self, batch, height, width):
         if self.weights is None:
             self.load_weights()
         key = (batch, height, width, self.dtype)
         if key not in self._engines:
-            self._engines[key] = Engine(self.model_name, self.weights, batch, height, width, self.dtype)
+            self._engines[key] = Engine(self.model_name, self.weights, batch, height, width, self.dtype,
+                                        **self._engine_kwargs())
         return self._engines[key]
+
+    def _engine_kwargs(self):
+        return {}
 
     # ---- graph: same signature as the reference's model()/loss() --------------------------------
     def model(self, inputs, training_schedule=LONG_SCHEDULE, trainable=True):

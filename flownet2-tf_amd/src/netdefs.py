@@ -3,8 +3,9 @@ src/flownet_s/flownet_s.py:39-104, flownet_c/flownet_c.py:30-107,
 flownet_sd/flownet_sd.py:29-103, flownet2/flownet2.py:61-98) as data.
 
 Each entry: (name, kind, k, stride, pad, cin, cout, act).  kind is "conv"
-(slim.conv2d on an explicitly padded input, bias present) or "deconv"
-(slim.conv2d_transpose k=4 s=2 VALID + antipad(1), no bias).  Variable names are
+(slim.conv2d on an explicitly padded input) or "deconv" (slim.conv2d_transpose
+k=4 s=2 VALID + antipad(1)).  Whether a layer owns a ``biases`` variable is what
+the arg_scopes of its model file say -- ``has_bias`` below.  Variable names are
 ``<scope>/<name>/weights|biases`` with HWIO (conv) / HW-O-I (deconv) layout
  so converted TF checkpoints can be loaded unchanged.
 """
@@ -71,6 +72,30 @@ def fusion_layers():
             ("fuse_upsample_flow1to0", "deconv", 4, 2, 1, 2, 2, LINEAR),
             ("fuse_interconv0", "conv", 3, 1, 1, 82, 16, LINEAR),
             ("predict_flow0", "conv", 3, 1, 1, 16, 2, LINEAR)]
+
+
+def has_bias(model, name, kind, no_deconv_biases=True):
+    """Does the reference graph create ``<scope>/<name>/biases``?  slim's default is
+    biases_initializer=zeros (a variable exists) unless an arg_scope or the call says None:
+
+      * every slim.conv2d of S / C / SD / fusion: bias (no model file overrides it);
+      * slim.conv2d_transpose inside the refinement scopes of S / C / SD: biases_initializer=None
+        (flownet_s.py:53, flownet_c.py:58, flownet_sd.py:44) -> deconvN and upsample_flowXtoY have none;
+      * the FlowNet2 fusion net opens NO such scope (flownet2.py:50-57): fuse_deconv1/0 and
+        fuse_upsample_flow2to1/1to0 (flownet2.py:66-89) DO carry biases, and the Caffe converter writes them
+        (scripts/caffe/convert_caffe_weights_to_npy.py:454-459, :492-496);
+      * FlowNetS_interp (flownet_s_interp.py:78-126): predict_flowN and deconvN take
+        ``biases_initializer = None if no_deconv_biases else zeros``; upsample_flowXtoY always None."""
+    fused = name.startswith("fuse_")
+    if kind == "conv":
+        if model == "FlowNetS_interp" and name.startswith("predict_flow"):
+            return not no_deconv_biases
+        return True
+    if fused:
+        return True
+    if model == "FlowNetS_interp" and name.startswith("deconv"):
+        return not no_deconv_biases
+    return False
 
 
 def model_scopes(model):

@@ -61,6 +61,49 @@ def crc32c(data, crc=0):
     return c ^ 0xFFFFFFFF
 
 
+def _gf2_apply(cols, r):
+    """cols[i] = image of bit i under a GF(2)-linear map of 32-bit registers; r: uint32 array."""
+    out = np.zeros_like(r)
+    for i in range(32):
+        out ^= np.where((r >> np.uint32(i)) & np.uint32(1), cols[i], np.uint32(0)).astype(np.uint32)
+    return out
+
+
+def crc32c_lanes(data, lanes=4096):
+    """CRC-32C of a large buffer in NumPy, for hosts without the HIP library: the buffer is cut into `lanes`
+    contiguous pieces whose register updates run side by side (one table look-up per byte position, vectorised over
+    the lanes; the update is GF(2)-linear in the register, so every lane but the first starts from 0), and the lane
+    registers are folded pairwise with the 'append m zero bytes' operator, squared per round.  Tens of MB/s against
+    ~1 MB/s of the byte loop; same value as crc32c()."""
+    buf = np.frombuffer(memoryview(data), dtype=np.uint8)
+    n = buf.size
+    m = n // lanes
+    if m < 16:
+        return crc32c(data)
+    body = buf[:lanes * m].reshape(lanes, m)
+    reg = np.zeros(lanes, np.uint32)
+    reg[0] = 0xFFFFFFFF
+    tab = _CRC_T.astype(np.uint32)
+    for j in range(m):
+        reg = tab[(reg ^ body[:, j]) & np.uint32(0xFF)] ^ (reg >> np.uint32(8))
+    # operator Z: one zero byte; cols of Z^m by square-and-multiply
+    one = (np.uint32(1) << np.arange(32, dtype=np.uint32)).astype(np.uint32)
+    z1 = tab[one & np.uint32(0xFF)] ^ (one >> np.uint32(8))
+    op, sq, e = one.copy(), z1, m
+    while e:
+        if e & 1:
+            op = _gf2_apply(sq, op)
+        sq = _gf2_apply(sq, sq)
+        e >>= 1
+    while reg.size > 1:  # (left, right) -> Z^len(right) left ^ right; lanes is a power of two
+        reg = _gf2_apply(op, reg[0::2]) ^ reg[1::2]
+        op = _gf2_apply(op, op)
+    c = int(reg[0])
+    for b in bytes(buf[lanes * m:]):
+        c = _CRC_L[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
 def mask_crc(crc):
     """leveldb/TF store crcs "masked": rotate right by 15 and add a constant (crc32c.h)."""
     return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + _MASK_DELTA) & 0xFFFFFFFF
@@ -439,11 +482,31 @@ def save_tf_checkpoint(prefix, variables):
 
 
 def _crc_bulk(raw):
-    """CRC-32C of a tensor's bytes: the library's slicing-by-8 host routine (fn2_crc32c, ~2 GB/s); the pure-Python
-    loop above is ~1 MB/s and only serves the few-KB table blocks."""
+    """CRC-32C of a tensor's bytes: the library's slicing-by-8 host routine (fn2_crc32c, ~2 GB/s) when
+    libflownet2_hip.so is built; without it (a host that only converts checkpoints / records: nothing here needs a
+    GPU) the lane-parallel NumPy form.  The pure-Python loop is ~1 MB/s and only serves the few-KB table blocks."""
     if len(raw) < 65536:
         return crc32c(raw)
+    fn = _host_crc()
+    if fn is None:
+        return crc32c_lanes(raw)
     import ctypes as C
-    from . import _hip
     buf = np.frombuffer(raw, dtype=np.uint8)
-    return int(_hip.lib().fn2_crc32c(buf.ctypes.data_as(C.c_void_p), buf.size, 0))
+    return int(fn(buf.ctypes.data_as(C.c_void_p), buf.size, 0))
+
+
+_HOST_CRC = []
+
+
+def _host_crc():
+    """fn2_crc32c of the built library, or None (library or torch missing); FN2_NO_HOST_CRC=1 forces None."""
+    if not _HOST_CRC:
+        fn = None
+        if not os.environ.get("FN2_NO_HOST_CRC"):
+            try:
+                from . import _hip
+                fn = _hip.lib().fn2_crc32c
+            except Exception:  # HipLibraryMissing, OSError (unloadable .so), ImportError (no torch)
+                fn = None
+        _HOST_CRC.append(fn)
+    return _HOST_CRC[0]

@@ -473,9 +473,23 @@ class FlowNetSTrainer:
         the reference interleaves with training (Net.train's custom train_step_fn, net.py:1300-1380: every
         `valid_iters` steps, average EPE over the validation batches)."""
         total, count = 0.0, 0
+
+        def crop(x):
+            """Centre crop of a [N,H,W,C] batch to the engine's size (validation frames are not augmented, so they
+            arrive at the dataset's size while the engine has the augmentation crop's, dataloader.FLYING_CHAIRS_PREPROCESS)."""
+            t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+            h, w = int(t.shape[1]), int(t.shape[2])
+            if (h, w) == (self.H, self.W):
+                return t
+            if h < self.H or w < self.W:
+                raise ValueError("validation frames %dx%d are smaller than the trainer's %dx%d" % (h, w, self.H, self.W))
+            y0, x0 = (h - self.H) // 2, (w - self.W) // 2
+            return t[:, y0:y0 + self.H, x0:x0 + self.W]
+
         for i, (a, b, gt) in enumerate(batches):
             if max_batches is not None and i >= max_batches:
                 break
+            a, b, gt = crop(a), crop(b), crop(gt)
             self.eng.set_inputs(a, b)
             self.eng.launch()
             gt_dev = (gt if isinstance(gt, torch.Tensor) else torch.as_tensor(np.asarray(gt))).to(

@@ -21,8 +21,10 @@ def init_weights(model, seed=1234, flow_gain=0.25, bias_std=0.02, head_biases=No
     sqrt(1/fan_in); flow heads scaled by ``flow_gain`` so that 20*predict_flow2
     spans several pixels (flow_warp then sees in- and out-of-range targets).
     Small random biases exercise the bias path (the reference initialises them to 0).
-    head_biases=False: no predict_flowN biases (FlowNetS_interp's default no_deconv_biases=True,
-    flownet_s_interp.py:12-14, :86-95)."""
+    head_biases: FlowNetS_interp only -- False (its default) = the class default no_deconv_biases=True: neither
+    predict_flowN nor deconvN get biases (flownet_s_interp.py:12-14, :78-126); True = no_deconv_biases=False.
+    Exactly the variables netdefs.has_bias declares are emitted -- including the biases of the FlowNet2 fusion
+    net's four transposed convs (flownet2.py:50-89), non-zero so that a path dropping them fails its test."""
     if head_biases is None:
         head_biases = model != "FlowNetS_interp"
     rng = np.random.default_rng(seed)
@@ -35,13 +37,17 @@ def init_weights(model, seed=1234, flow_gain=0.25, bias_std=0.02, head_biases=No
                 if name.startswith("predict_flow"):
                     std *= flow_gain
                 w[f"{scope}/{name}/weights"] = (rng.standard_normal((k, k, cin, cout)) * std).astype(np.float32)
-                b = (rng.standard_normal((cout,)) * bias_std).astype(np.float32)
-                if head_biases or not name.startswith("predict_flow"):
+                b = (rng.standard_normal((cout,)) * bias_std).astype(np.float32)  # drawn even when unused: keeps the
+                if netdefs.has_bias(model, name, kind, not head_biases):           # stream of the later layers fixed
                     w[f"{scope}/{name}/biases"] = b
             else:
                 fan_in = 4 * cin  # each output pixel of a k4 s2 transposed conv sees 2x2 taps
                 std = np.sqrt((2.0 if act else 1.0) / fan_in)
                 w[f"{scope}/{name}/weights"] = (rng.standard_normal((k, k, cout, cin)) * std).astype(np.float32)
+                if netdefs.has_bias(model, name, kind, not head_biases):
+                    # own generator: the weights of every layer stay what earlier rounds' fixtures were made with
+                    brng = np.random.default_rng([seed, len(w)])
+                    w[f"{scope}/{name}/biases"] = (brng.standard_normal((cout,)) * 5 * bias_std).astype(np.float32)
     return w
 
 
@@ -56,9 +62,10 @@ def load_npz(path):
 
 def load_npy(path):
     """The `.npy` the reference's Caffe converter writes (scripts/caffe/convert_caffe_weights_to_npy.py:489-496):
-    np.save of a dict {<tf variable>/weights (HWIO; transposed convs HW-O-I), <tf variable>/biases}.  Entries the
-    graphs never read (Caffe's deconvolution biases: biases_initializer=None at flownet_s.py:53) are kept and
-    ignored by the engine."""
+    np.save of a dict {<tf variable>/weights (HWIO; transposed convs HW-O-I), <tf variable>/biases}.  Biases of
+    transposed convs the reference graph builds with biases_initializer=None (flownet_s.py:53, flownet_c.py:58,
+    flownet_sd.py:44) are not graph variables: the engine lists them in Engine.ignored_variables and warns; those of
+    the FlowNet2 fusion net (flownet2.py:50-89) ARE variables and are applied."""
     obj = np.load(path, allow_pickle=True)
     if obj.dtype != object or obj.shape != ():
         raise ValueError("%s does not hold a pickled {name: array} dict" % path)

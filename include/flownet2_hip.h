@@ -125,7 +125,8 @@ int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in
  * bf16: v_mfma_f32_16x16x32_bf16), zero padding / bias / LeakyReLU / concat-slice write fused.
  *   kind 0: slim.conv2d(pad(x,p), Cout, k, stride, 'VALID')        (flownet_s.py:39-50)
  *   kind 1: antipad(slim.conv2d_transpose(x, Cout, 4, 2, 'VALID')) (flownet_s.py:53-63), computed as
- *           four 2x2 stride-1 phase convolutions; no bias in the reference.
+ *           four 2x2 stride-1 phase convolutions; bias NULL inside the refinement scopes (biases_initializer=None,
+ *           flownet_s.py:53), non-NULL for the FlowNet2 fusion net's fuse_deconv1 / fuse_deconv0 (flownet2.py:66-84).
  *   kind 2: the same convolution as kind 0 for the few-channel network inputs (3/6/11/12 channels): the
  *           input view is the WHOLE pre-padded buffer [n, H+2p, W+2p, cs] (in.c == in.cs, in.c0 == 0,
  *           desc.pad == 0), and the kw horizontal taps x cs channels of one kernel row are read as ONE
@@ -179,9 +180,12 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream);
  * 1x1 convolution with 18 outputs t[pix][tap*2+co] (weight w1x1[ci][tap*2+co] = w[ky][kx][ci][co]) into an fp32
  * scratch tensor, then this call: out[n,y,x,co] = bias[co] + sum_taps t[n,y+ky-1,x+kx-1][tap*2+co].  out dense [n,h,w,2]. */
 int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out, int n, int h, int w, void* stream);
-/* upsample_flowXtoY: 2->2 channel conv-transpose 4x4 s2 crop 1, linear, no bias (flownet_s.py:60-63).
- * in: fp32 [n,h,w,2] dense; w: fp32 [4][4][2 out][2 in] (reference HW-O-I layout); out: view with c=2. */
-int fn2_upsample_flow(const float* in, const float* w, const fn2_tensor* out, int n, int h, int wd,
+/* upsample_flowXtoY: 2->2 channel conv-transpose 4x4 s2 crop 1, linear (flownet_s.py:60-63).
+ * in: fp32 [n,h,w,2] dense; w: fp32 [4][4][2 out][2 in] (reference HW-O-I layout); out: view with c=2.
+ * bias: fp32 [2] or NULL.  NULL inside the refinement scopes of S / C / SD (biases_initializer=None, flownet_s.py:53,
+ * flownet_c.py:58, flownet_sd.py:44); the FlowNet2 fusion net's fuse_upsample_flow2to1 / 1to0 carry one
+ * (flownet2.py:50-57 opens no such scope; :70-73, :86-89). */
+int fn2_upsample_flow(const float* in, const float* w, const float* bias, const fn2_tensor* out, int n, int h, int wd,
                       void* stream);
 
 /* The four "network input" builders below write the INTERIOR of a view whose h, w include a zero border of

@@ -24,29 +24,37 @@ class _Scope:
         # slim.conv2d under the arg_scope of flownet_s.py:26-37: bias present,
         # LeakyReLU unless activation_fn=None
         w = self.w[f"{self.s}/{name}/weights"]
-        b = self.w.get(f"{self.s}/{name}/biases")  # absent: biases_initializer=None (flownet_s_interp.py:86-95)
+        key = f"{self.s}/{name}/biases"
+        # every slim.conv2d of the model files has its bias variable; only FlowNetS_interp's heads may be built
+        # with biases_initializer=None (flownet_s_interp.py:78-126) -- then the entry is absent
+        b = self.w[key] if (key in self.w or not name.startswith("predict_flow")) else None
         return nn.conv2d(x, w, b, stride=stride, padding=padding,
                          activation=nn.leaky_relu if act else None)
 
-    def deconv(self, x, name, act=True):
-        # antipad(slim.conv2d_transpose(.., 4, stride=2)) with
-        # biases_initializer=None (flownet_s.py:53-63)
+    def deconv(self, x, name, act=True, bias=False):
+        # antipad(slim.conv2d_transpose(.., 4, stride=2)).  bias=False: the call sits inside a
+        # biases_initializer=None scope (flownet_s.py:53, flownet_c.py:58, flownet_sd.py:44) -- a
+        # ``biases`` entry of the checkpoint, if any, is not a graph variable and is not read.
+        # bias=True: slim's default zeros-initialised bias variable exists and MUST be in the checkpoint
+        # (the FlowNet2 fusion net, flownet2.py:50-89; FlowNetS_interp's deconvN with no_deconv_biases=False).
         w = self.w[f"{self.s}/{name}/weights"]
-        return nn.conv2d_transpose(x, w, stride=2, crop=1,
+        b = self.w[f"{self.s}/{name}/biases"] if bias else None
+        return nn.conv2d_transpose(x, w, stride=2, crop=1, bias=b,
                                    activation=nn.leaky_relu if act else None)
 
 
-def _refine(sc, feats, interconv=False):
+def _refine(sc, feats, interconv=False, deconv_bias=False):
     """The 4-level refinement decoder shared by S, C and SD
     (flownet_s.py:52-104; flownet_sd.py:45-103 adds interconvN).
-    ``feats`` = (conv6_1, conv5_1, conv4_1, conv3_1, skip2)."""
+    ``feats`` = (conv6_1, conv5_1, conv4_1, conv3_1, skip2).  deconv_bias: FlowNetS_interp built with
+    no_deconv_biases=False gives deconvN (not upsample_flowXtoY) a bias (flownet_s_interp.py:84-126)."""
     top, skips = feats[0], feats[1:]
     preds = {}
     pf = sc.conv(top, "predict_flow6", act=False)
     preds["predict_flow6"] = pf
     cur = top
     for lvl, skip in zip((5, 4, 3, 2), skips):
-        dec = sc.deconv(cur, f"deconv{lvl}")
+        dec = sc.deconv(cur, f"deconv{lvl}", bias=deconv_bias)
         up = sc.deconv(pf, f"upsample_flow{lvl + 1}to{lvl}", act=False)
         cur = np.concatenate([skip, dec, up], axis=3)  # [skip | deconv | up], :64
         head_in = sc.conv(cur, f"interconv{lvl}", act=False) if interconv else cur
@@ -61,7 +69,7 @@ def _finish(preds, height, width, scale):
     return preds
 
 
-def flownet_s(weights, inputs, scope="FlowNetS"):
+def flownet_s(weights, inputs, scope="FlowNetS", deconv_bias=False):
     """FlowNetS.model (flownet_s.py:14-120)."""
     a = np.asarray(inputs["input_a"], F64)
     _, H, W, _ = a.shape
@@ -78,19 +86,26 @@ def flownet_s(weights, inputs, scope="FlowNetS"):
     c4_1 = sc.conv(sc.conv(c3_1, "conv4", 2), "conv4_1")
     c5_1 = sc.conv(sc.conv(c4_1, "conv5", 2), "conv5_1")
     c6_1 = sc.conv(sc.conv(c5_1, "conv6", 2), "conv6_1")
-    preds = _refine(sc, (c6_1, c5_1, c4_1, c3_1, c2))
+    preds = _refine(sc, (c6_1, c5_1, c4_1, c3_1, c2), deconv_bias=deconv_bias)
     return _finish(preds, H, W, 20.0)  # :107-111
 
 
-def flownet_s_interp(weights, inputs, scope="FlowNetS"):
+def flownet_s_interp(weights, inputs, scope="FlowNetS", no_deconv_biases=None):
     """FlowNetS_interp.model (flownet_s_interp/flownet_s_interp.py:21-156): the FlowNetS tower on
     [input_a | 0.05 * sparse_flow | matches_a] (:34-38), variable scope 'FlowNetS' (:23); with the class default
-    no_deconv_biases=True the predict_flow layers have no biases (:86-95)."""
+    no_deconv_biases=True neither the predict_flow layers nor deconvN have biases, with False both have
+    (:78-126); upsample_flowXtoY never.  None: as the weights say (predict_flow6/biases present or not)."""
+    if no_deconv_biases is None:
+        no_deconv_biases = f"{scope}/predict_flow6/biases" not in weights
+    if no_deconv_biases:  # the heads' `biases` of a plain FlowNetS checkpoint are not variables of this graph
+        weights = {k: v for k, v in weights.items()
+                   if not (k.startswith(scope + "/predict_flow") and k.endswith("/biases"))}
     m = np.asarray(inputs["matches_a"], F64)
     if m.ndim == 3:
         m = m[..., None]
     second = np.concatenate([np.asarray(inputs["sparse_flow"], F64) * 0.05, m], axis=3)
-    return flownet_s(weights, {"input_a": inputs["input_a"], "input_b": second}, scope)
+    return flownet_s(weights, {"input_a": inputs["input_a"], "input_b": second}, scope,
+                     deconv_bias=not no_deconv_biases)
 
 
 def flownet_c(weights, inputs, scope="FlowNetC"):
@@ -176,11 +191,12 @@ def flownet2(weights, inputs, scope="FlowNet2"):
     f1_1 = sc.conv(sc.conv(f0, "fuse_conv1", 2), "fuse_conv1_1")
     f2_1 = sc.conv(sc.conv(f1_1, "fuse_conv2", 2), "fuse_conv2_1")
     pf2 = sc.conv(f2_1, "predict_flow2", act=False)
-    cat1 = np.concatenate([f1_1, sc.deconv(f2_1, "fuse_deconv1"),
-                           sc.deconv(pf2, "fuse_upsample_flow2to1", act=False)], axis=3)
+    # the fusion arg_scope (:50-57) sets no biases_initializer=None: all four transposed convs have biases
+    cat1 = np.concatenate([f1_1, sc.deconv(f2_1, "fuse_deconv1", bias=True),
+                           sc.deconv(pf2, "fuse_upsample_flow2to1", act=False, bias=True)], axis=3)
     pf1 = sc.conv(sc.conv(cat1, "fuse_interconv1", act=False), "predict_flow1", act=False)
-    cat0 = np.concatenate([f0, sc.deconv(cat1, "fuse_deconv0"),
-                           sc.deconv(pf1, "fuse_upsample_flow1to0", act=False)], axis=3)
+    cat0 = np.concatenate([f0, sc.deconv(cat1, "fuse_deconv0", bias=True),
+                           sc.deconv(pf1, "fuse_upsample_flow1to0", act=False, bias=True)], axis=3)
     pf0 = sc.conv(sc.conv(cat0, "fuse_interconv0", act=False), "predict_flow0", act=False)
     flow = nn.resize_bilinear_align_corners(pf0, (H, W))  # identity size, :100-101
     return {"predict_flow0": pf0, "flow": flow}

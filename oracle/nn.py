@@ -57,10 +57,12 @@ def conv2d(x, w, b=None, stride=1, padding=0, activation=None, dtype=np.float64)
     return out
 
 
-def conv2d_transpose(x, w, stride=2, crop=1, activation=None, dtype=np.float64):
+def conv2d_transpose(x, w, stride=2, crop=1, activation=None, dtype=np.float64, bias=None):
     """antipad(slim.conv2d_transpose(x, Cout, 4, stride=2, padding='VALID'))
-    without bias (flownet_s.py:53-63): full[n, s*y+ky, s*x+kx, o] +=
-    x[n,y,x,i] * w[ky,kx,o,i] (w is HW-O-I), size s(H-1)+k; then crop."""
+    (flownet_s.py:53-63): full[n, s*y+ky, s*x+kx, o] += x[n,y,x,i] * w[ky,kx,o,i]
+    (w is HW-O-I), size s(H-1)+k; + bias where the layer has one (slim adds it before
+    the activation; none under biases_initializer=None, flownet_s.py:53 -- the FlowNet2
+    fusion net's transposed convs have one, flownet2.py:50-89); then crop."""
     x = np.asarray(x, dtype)
     w = np.asarray(w, dtype)
     N, H, W, Cin = x.shape
@@ -71,6 +73,8 @@ def conv2d_transpose(x, w, stride=2, crop=1, activation=None, dtype=np.float64):
         for kx in range(kw):
             full[:, ky:ky + stride * (H - 1) + 1:stride, kx:kx + stride * (W - 1) + 1:stride, :] += \
                 x @ w[ky, kx].T
+    if bias is not None:
+        full = full + np.asarray(bias, dtype)
     out = antipad(full, crop) if crop else full
     if activation is not None:
         out = activation(out)

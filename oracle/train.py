@@ -54,7 +54,10 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
 
     def deconv(x, name, act=True):
         w = P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1)  # [ky,kx,o,i] -> [i,o,ky,kx]
-        y = F.conv_transpose2d(x, w, stride=2, padding=1)
+        # biases_initializer=None in S / SD (flownet_s.py:53, flownet_sd.py:44); FlowNetS_interp built with
+        # no_deconv_biases=False gives deconvN -- never upsample_flowXtoY -- a bias (flownet_s_interp.py:84-126)
+        b = P.get(f"{scope}/{name}/biases") if (model == "FlowNetS_interp" and name.startswith("deconv")) else None
+        y = F.conv_transpose2d(x, w, b, stride=2, padding=1)
         if act_grads is not None:
             acts[name + "/pre"] = y
         return _leaky(y, None if signs is None else signs.get(name)) if act else y

@@ -157,6 +157,21 @@ def test_deconv_f32_matches_oracle(cin, cout, H, W):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 32, 12, 16), (162, 16, 24, 32), (1024, 512, 3, 4), (72, 24, 5, 7)])
+def test_deconv_with_bias_matches_oracle(cin, cout, H, W, dtype):
+    """Transposed conv WITH a bias, added before the LeakyReLU as slim.conv2d_transpose does: the FlowNet2 fusion net's
+    fuse_deconv1 (128 -> 32) and fuse_deconv0 (162 -> 16) (flownet2.py:66-84, no biases_initializer=None scope at
+    :50-57); a split-K geometry (bias applied by the finalize pass) and an odd-sized one as well."""
+    x = rnd((2, H, W, cin), 5)
+    w = rnd((4, 4, cout, cin), 6, (2.0 / (4 * cin)) ** 0.5)
+    b = rnd((cout,), 9, 0.5)
+    want = refnn.conv2d_transpose(x, w, activation=refnn.leaky_relu, bias=b)
+    assert np.abs(want - refnn.conv2d_transpose(x, w, activation=refnn.leaky_relu)).max() > 0.1  # the bias matters
+    got = run_conv(x, w, b, "deconv", 4, 2, 1, True, dtype, cout_off=8, out_f32=True)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("k,s,p,cin,cout,H,W", CONV_CASES[:6])
 def test_conv_bf16_matches_oracle_on_bf16_rounded_inputs(k, s, p, cin, cout, H, W):
     """bf16 path: identical to the fp64 oracle fed the bf16-rounded inputs/weights, up to fp32
@@ -288,10 +303,15 @@ def test_upsample_flow_matches_oracle():
     out = torch.full((2, 10, 14, 8), 3.0, device="cuda")
     v = _hip.view(out, 2, 4)
     xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()  # keep alive across the async launch
-    _hip.check(lib.fn2_upsample_flow(_hip.ptr(xd), _hip.ptr(wd), C.byref(v), 2, 5, 7, _hip.stream_ptr()))
+    _hip.check(lib.fn2_upsample_flow(_hip.ptr(xd), _hip.ptr(wd), None, C.byref(v), 2, 5, 7, _hip.stream_ptr()))
     res = out.cpu().numpy()
     np.testing.assert_allclose(res[..., 4:6], want, rtol=1e-5, atol=1e-5)
     assert np.all(res[..., :4] == 3.0) and np.all(res[..., 6:] == 3.0)
+    # with a bias: the FlowNet2 fusion net's fuse_upsample_flow2to1 / 1to0 (flownet2.py:70-73, :86-89)
+    bias = np.array([0.375, -1.25], np.float32)
+    bd = torch.from_numpy(bias).cuda()
+    _hip.check(lib.fn2_upsample_flow(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), C.byref(v), 2, 5, 7, _hip.stream_ptr()))
+    np.testing.assert_allclose(out.cpu().numpy()[..., 4:6], refnn.conv2d_transpose(x, w, bias=bias), rtol=1e-5, atol=1e-5)
 
 
 def test_conv_rejects_bad_descriptors():

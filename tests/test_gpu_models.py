@@ -109,6 +109,115 @@ def test_split_fp16_path_meets_parity_bar(model):
     assert e < EPE_TOL
 
 
+@pytest.mark.parametrize("model", ["FlowNetCS", "FlowNetCSS"])
+def test_stacked_nets_split_fp16(model):
+    """CS / CSS (flownet_cs.py:15-38, flownet_css.py:15-38) in the bench dtype."""
+    out, want = run(model, "f16x2", 1, 64, 64)
+    e = epe(out["flow"], want["flow"])
+    print(model, "f16x2 mean EPE vs oracle %.3e px" % e)
+    assert e < EPE_TOL
+
+
+_SUBFLOWS = {"flow_c": "F2/CSS/CS/C/flow", "flow_cs": "F2/CSS/CS/S/flow", "flow_css": "F2/CSS/S/flow", "flow_sd": "F2/SD/flow"}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+@pytest.mark.parametrize("shape", ["384x512", "448x1024"])
+def test_flownet2_full_size_against_the_committed_fixture(golden_dir, shape, dtype):
+    """BASELINE configs 3 (512x384) and 5 (Sintel 1024x436 zero-padded to 448 rows, net.py:373-388): the FlowNet2 full
+    stack in the fp32 path and in the bench dtype against oracle outputs committed as
+    tests/golden/flownet2_<shape>_golden.npz (4096 probe pixels of the final flow and of the C / CS / CSS / SD flows;
+    generated by tests/golden/make_golden_flownet2.py with the fusion biases non-zero).  No oracle run on the box."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_flownet2 as gen
+    from src import weights as W
+    from src.engine import Engine
+    g = np.load(os.path.join(golden_dir, "flownet2_%s_golden.npz" % shape))
+    a, b = gen.inputs(shape)
+    H, Wd, _ = gen.SHAPES[shape]
+    eng = Engine("FlowNet2", W.init_weights("FlowNet2", gen.SEED_W), 1, H, Wd, dtype)
+    flow = eng(a, b)["flow"].float().cpu().numpy()
+    ys, xs = g["probe_y"], g["probe_x"]
+    for key, buf in _SUBFLOWS.items():
+        e = epe(eng.bufs[buf].float().cpu().numpy()[0, ys, xs], g[key])
+        print("FlowNet2 %s %s %s: mean EPE over the probes %.3e px" % (shape, dtype, key, e))
+        assert e < EPE_TOL, key
+    e = epe(flow[0, ys, xs], g["flow"])
+    print("FlowNet2 %s %s final flow: mean EPE over the probes %.3e px (mean |flow| %.3f px)" % (shape, dtype, e, float(g["mean_mag"])))
+    assert e < EPE_TOL
+    assert np.isfinite(flow).all()
+
+
+def test_flownet2_fusion_biases_are_applied():
+    """The fusion net's four transposed convs carry biases (flownet2.py:50-89: no biases_initializer=None scope): with
+    them zeroed the flow moves by far more than the parity tolerance, and a checkpoint lacking one is an error."""
+    from src import weights as W
+    from src.engine import Engine
+    wts = W.init_weights("FlowNet2", 1234)
+    a, b = images(1, 64, 64, 0)
+    base = Engine("FlowNet2", wts, 1, 64, 64, "f32")(a, b)["flow"].float().cpu().numpy()
+    fused = [k for k in wts if k.startswith("FlowNet2/fuse_") and ("deconv" in k or "upsample" in k) and k.endswith("/biases")]
+    assert len(fused) == 4
+    zeroed = dict(wts)
+    for k in fused:
+        zeroed[k] = np.zeros_like(wts[k])
+    moved = Engine("FlowNet2", zeroed, 1, 64, 64, "f32")(a, b)["flow"].float().cpu().numpy()
+    assert epe(base, moved) > 3 * EPE_TOL
+    want = refm.flownet2(zeroed, {"input_a": a, "input_b": b})["flow"]
+    assert epe(moved, want) < EPE_TOL
+    missing = {k: v for k, v in wts.items() if k != "FlowNet2/fuse_upsample_flow1to0/biases"}
+    with pytest.raises(KeyError):
+        Engine("FlowNet2", missing, 1, 64, 64, "f32")
+
+
+def test_engine_reports_variables_no_layer_reads():
+    """A variable under the model's scope that no layer consumes is an error (silently dropped tensors are how the
+    fusion biases went missing); Caffe's deconvolution biases of a converted FlowNetS .npy are NOT graph variables
+    (biases_initializer=None, flownet_s.py:53): ignored with a warning, as the reference's Saver ignores them; Adam
+    slots and counters of a training checkpoint pass."""
+    from src import weights as W
+    from src.engine import Engine
+    wts = W.init_weights("FlowNetS", 3)
+    a, b = images(1, 64, 64, 1)
+    base = Engine("FlowNetS", wts, 1, 64, 64, "f32")(a, b)["flow"].clone()
+    stray = dict(wts)
+    stray["FlowNetS/conv7/weights"] = np.zeros((3, 3, 8, 8), np.float32)
+    with pytest.raises(ValueError, match="conv7"):
+        Engine("FlowNetS", stray, 1, 64, 64, "f32")
+    assert Engine("FlowNetS", stray, 1, 64, 64, "f32", strict=False).stray_variables == ["FlowNetS/conv7/weights"]
+    caffe = dict(wts)
+    caffe["FlowNetS/deconv5/biases"] = np.ones(512, np.float32)
+    caffe["FlowNetS/upsample_flow6to5/biases"] = np.ones(2, np.float32)
+    caffe["FlowNetS/conv1/weights/Adam"] = np.zeros((7, 7, 6, 64), np.float32)
+    caffe["global_step"] = np.int64(7)
+    with pytest.warns(UserWarning, match="ignored"):
+        eng = Engine("FlowNetS", caffe, 1, 64, 64, "f32")
+    assert sorted(eng.ignored_variables) == ["FlowNetS/deconv5/biases", "FlowNetS/upsample_flow6to5/biases"]
+    assert torch.equal(eng(a, b)["flow"], base)
+
+
+def test_interp_with_deconv_biases():
+    """FlowNetS_interp(no_deconv_biases=False): predict_flowN and deconvN carry biases, upsample_flowXtoY none
+    (flownet_s_interp.py:78-126)."""
+    from src import weights as W
+    from src.engine import Engine
+    wts = W.init_weights("FlowNetS_interp", 5, head_biases=True)
+    rng = np.random.default_rng(2)
+    a = rng.random((1, 64, 64, 3), dtype=np.float32)
+    m = (rng.random((1, 64, 64, 1)) < 0.1).astype(np.float32)
+    sf = (rng.standard_normal((1, 64, 64, 2)) * 3).astype(np.float32) * m
+    eng = Engine("FlowNetS_interp", wts, 1, 64, 64, "f32", no_deconv_biases=False)
+    eng.set_inputs_interp(a, m, sf)
+    eng.launch()
+    got = eng.outputs["flow"].float().cpu().numpy()
+    want = refm.flownet_s_interp(wts, {"input_a": a, "matches_a": m, "sparse_flow": sf}, no_deconv_biases=False)["flow"]
+    assert epe(got, want) < EPE_TOL
+    nob = {k: (np.zeros_like(v) if "/deconv" in k and k.endswith("/biases") else v) for k, v in wts.items()}
+    assert epe(refm.flownet_s_interp(nob, {"input_a": a, "matches_a": m, "sparse_flow": sf}, no_deconv_biases=False)["flow"],
+               want) > 3 * EPE_TOL   # the deconv biases matter in this test
+
+
 def test_split_fp16_full_size_flownet_c():
     out, want = run("FlowNetC", "f16x2", 1, 384, 512)
     e = epe(out["flow"], want["flow"])

@@ -40,6 +40,20 @@ def test_correlation_matches_oracle(surf, shape, args):
     assert gt.is_cuda and torch.equal(gt.cpu(), torch.from_numpy(got))
 
 
+def test_correlation_at_the_flownet_c_call_site_size(surf):
+    """The drop-in op at the REAL call-site size of FlowNetC at 512x384 (flownet_c.py:40: conv3 outputs N x 48 x 64 x 256
+    -> N x 48 x 64 x 441), batch 2, against the oracle; plus the size-independent properties: bilinearity in a,
+    and out[..., centre displacement] = mean_c a*b."""
+    a, b = rnd((2, 48, 64, 256), 3), rnd((2, 48, 64, 256), 4)
+    want = ref.correlation(a, b, 1, 20, 1, 2, 20)
+    got = surf[0](a, b, 1, 20, 1, 2, 20)
+    assert got.shape == (2, 48, 64, 441)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(got[..., 220], (a * b).mean(-1), rtol=1e-5, atol=2e-6)   # displacement (0, 0)
+    got2 = surf[0]((2 * a).astype(np.float32), b, 1, 20, 1, 2, 20)
+    np.testing.assert_array_equal(got2, 2 * got)  # scaling by a power of two is exact in every summation order
+
+
 def test_correlation_validation(surf):
     a = rnd((1, 4, 4, 3), 0)
     with pytest.raises(ValueError):

@@ -211,7 +211,10 @@ def test_training_cli_pipeline(tmp_path, golden_dir):
     assert a0.shape == (2, 384, 512, 3) and np.array_equal(f0[0].cpu().numpy(), flowlib.read_flow(os.path.join(s, "0flow.flo")))
     flags = types.SimpleNamespace(list=str(lst), out=str(tmp_path / "ckpt"), checkpoint=None, steps=3, batch=2, dtype="f16x2",
                                   augment=True, height=384, width=512, seed=7, log_every=1, save_every=2, report_l2=True,
-                                  ckpt_format="npz")
+                                  ckpt_format="npz",
+                                  # default --augment (engine at the 384 x 448 crop) TOGETHER with a validation list of
+                                  # 384 x 512 frames: evaluate() centre-crops them (this combination raised in round 1)
+                                  val_list=str(lst), val_every=2, val_batches=1)
     tr = cli.main(flags)
     assert tr.step_count == 3
     saved = W.load_npz(str(tmp_path / "ckpt" / "flownet_s-3.npz"))
@@ -336,6 +339,38 @@ def test_flownet_s_interp_gradients_match_oracle(mode):
     # 'hard': an EPE value within fp32 rounding of the k-th largest may fall on the other side of the cut than in
     # float64 (one pixel of a level in or out of the mask)
     assert worst < (2e-5 if mode != "hard" else 2e-3), worst
+
+
+@pytest.mark.gpu
+def test_flownet_s_interp_gradients_with_deconv_biases():
+    """FlowNetS_interp(no_deconv_biases=False) (flownet_s_interp.py:84-126): predict_flowN AND deconvN carry (trainable)
+    biases, upsample_flowXtoY none; every filter and bias gradient against the float64 oracle."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetS_interp", 9, head_biases=True)
+    a, _, gt = data(2, 128, 128, 4)
+    rng = np.random.default_rng(5)
+    matches = (rng.random((2, 128, 128, 1)) < 0.05).astype(np.float32)
+    sparse = (gt * matches).astype(np.float32)
+    tr = FlowNetSTrainer(wts, 2, 128, 128, dtype="f32", model="FlowNetS_interp")
+    assert tr.eng.no_deconv_biases is False
+    loss = float(tr.forward_backward_interp(a, matches, sparse, gt).item())
+    b_equiv = np.concatenate([sparse * np.float32(0.05), matches], axis=3)
+    want_loss, grads, _ = reft.flownet_s_loss_and_grads(wts, a, b_equiv, gt, signs=device_signs(tr), model="FlowNetS_interp")
+    assert abs(loss - want_loss) < 2e-5 * abs(want_loss), (loss, want_loss)
+    worst, n_deconv_b = 0.0, 0
+    for rec in tr.eng.layers:
+        name = f"{rec['scope']}/{rec['name']}"
+        got = rec["dw"].cpu().numpy()
+        want = (grads[name + "/weights"].astype(np.float32).reshape(-1) if rec["kind"] == "upflow"
+                else packed_grad(rec, grads[name + "/weights"]).reshape(-1))
+        worst = max(worst, np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+        assert (rec.get("b") is not None) == (rec["kind"] != "upflow"), name
+        if rec.get("b") is not None:
+            gb, wb = rec["db"].cpu().numpy(), grads[name + "/biases"]
+            worst = max(worst, np.abs(gb - wb).max() / (np.abs(wb).max() + 1e-12))
+            n_deconv_b += rec["kind"] == 1
+    assert n_deconv_b == 4 and worst < 2e-5, worst
 
 
 @pytest.mark.gpu

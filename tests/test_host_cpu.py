@@ -270,3 +270,50 @@ def test_bench_traffic_lookup_resolves_committed_profiles():
         got = bench.stored_traffic(model, batch, "f16x2", kern)
         assert got is not None and got > 1e6, (model, kern)
     assert bench.stored_traffic("FlowNetC", 8, "f16x2", "no_such_kernel<1>") is None
+
+
+def test_bias_declarations_follow_the_reference_arg_scopes():
+    """netdefs.has_bias: slim's default (a zeros-initialised `biases` variable) unless a scope says
+    biases_initializer=None -- flownet_s.py:53, flownet_c.py:58, flownet_sd.py:44 do for conv2d_transpose, the FlowNet2
+    fusion net (flownet2.py:50-57) does not, FlowNetS_interp decides per constructor flag (flownet_s_interp.py:78-126)."""
+    from src import netdefs, weights as W
+    for model in ("FlowNetS", "FlowNetC", "FlowNetSD", "FlowNetCS", "FlowNetCSS"):
+        keys = W.init_weights(model, 1)
+        assert not any(("deconv" in k or "upsample_flow" in k) and k.endswith("/biases") for k in keys), model
+        assert all(k[:-len("weights")] + "biases" in keys for k in keys
+                   if k.endswith("/weights") and "deconv" not in k and "upsample_flow" not in k), model
+    w2 = W.init_weights("FlowNet2", 1)
+    fused = sorted(k for k in w2 if ("deconv" in k or "upsample_flow" in k) and k.endswith("/biases"))
+    assert fused == ["FlowNet2/fuse_deconv0/biases", "FlowNet2/fuse_deconv1/biases",
+                     "FlowNet2/fuse_upsample_flow1to0/biases", "FlowNet2/fuse_upsample_flow2to1/biases"]
+    assert w2["FlowNet2/fuse_deconv1/biases"].shape == (32,) and w2["FlowNet2/fuse_deconv0/biases"].shape == (16,)
+    assert all(np.abs(w2[k]).max() > 0 for k in fused)  # non-zero: a path that drops them fails its parity test
+    # the sub-networks inside FlowNet2 keep their bias-free transposed convs
+    assert "FlowNet2/FlowNetSD/deconv5/biases" not in w2 and "FlowNet2/FlowNetCSS/FlowNetS/deconv2/biases" not in w2
+    wi = W.init_weights("FlowNetS_interp", 1)                       # no_deconv_biases=True (the class default)
+    assert not any(("predict_flow" in k or "deconv" in k) and k.endswith("/biases") for k in wi)
+    wb = W.init_weights("FlowNetS_interp", 1, head_biases=True)     # no_deconv_biases=False
+    assert "FlowNetS/predict_flow4/biases" in wb and "FlowNetS/deconv3/biases" in wb
+    assert not any("upsample_flow" in k and k.endswith("/biases") for k in wb)
+    assert netdefs.has_bias("FlowNet2", "fuse_upsample_flow2to1", "deconv") and not netdefs.has_bias("FlowNetS", "deconv5", "deconv")
+    # the weights of every layer are what round-1 fixtures were generated with (bias draws do not shift the stream)
+    assert np.array_equal(W.init_weights("FlowNet2", 1)["FlowNet2/predict_flow0/weights"], w2["FlowNet2/predict_flow0/weights"])
+
+
+def test_oracle_fusion_transposed_convs_read_their_biases():
+    """oracle.models.flownet2's fusion part (flownet2.py:61-98): fuse_deconv1/0 and fuse_upsample_flow2to1/1to0 add their
+    biases (before the LeakyReLU, as slim does) and a checkpoint lacking one is an error, not a silent zero."""
+    from oracle import nn as refnn, models as refm
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 3, 4, 5))
+    w = rng.standard_normal((4, 4, 2, 5))
+    b = np.array([0.5, -2.0])
+    plain = refnn.conv2d_transpose(x, w)
+    np.testing.assert_allclose(refnn.conv2d_transpose(x, w, bias=b), plain + b, rtol=0, atol=1e-12)
+    act = refnn.conv2d_transpose(x, w, bias=b, activation=refnn.leaky_relu)
+    np.testing.assert_allclose(act, refnn.leaky_relu(plain + b), rtol=0, atol=1e-12)   # bias first, then LeakyReLU
+    sc = refm._Scope({"S/d/weights": w, "S/d/biases": b}, "S")
+    np.testing.assert_allclose(sc.deconv(x, "d", act=False, bias=True), plain + b, atol=1e-12)
+    np.testing.assert_allclose(sc.deconv(x, "d", act=False), plain, atol=1e-12)  # biases_initializer=None scope: not read
+    with pytest.raises(KeyError):
+        refm._Scope({"S/d/weights": w}, "S").deconv(x, "d", bias=True)

@@ -161,3 +161,17 @@ def test_weights_and_net_load_a_tf_checkpoint(tmp_path):
     net = FlowNetS()
     loaded = net.load_weights(prefix)
     np.testing.assert_array_equal(loaded["FlowNetS/conv3_1/weights"], wts["FlowNetS/conv3_1/weights"])
+
+
+def test_bulk_crc_without_the_hip_library(monkeypatch):
+    """Host-only conversion of checkpoints / records must not need libflownet2_hip.so: the lane-parallel NumPy CRC-32C
+    equals the byte loop (RFC 3720 check value included) and the library routine on ragged sizes."""
+    from src import tf_checkpoint as T
+    assert T.crc32c_lanes(b"123456789") == 0xE3069283
+    rng = np.random.default_rng(0)
+    for n in (65536, 65537, 100003, 4096 * 16 + 5, 300000):
+        raw = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert T.crc32c_lanes(raw) == T.crc32c(raw) == T._crc_bulk(raw), n
+    monkeypatch.setattr(T, "_HOST_CRC", [None])   # as on a host without the library
+    raw = rng.integers(0, 256, 70001, dtype=np.uint8).tobytes()
+    assert T._crc_bulk(raw) == T.crc32c(raw)
