@@ -115,7 +115,41 @@ static int check_out16(const fn2_tensor* out, int c, const char* what) {
 
 using namespace fn2;
 
+// uint8 image bytes -> fp32 through a 256-entry table: what Net.adapt_x does on the host (src/net.py:338-345:
+// `x / 255.0` in float64 when the image's max exceeds 1, else the values as they are, then the float32 feed) done
+// after the copy, so the host link carries one byte per channel instead of four.  The table IS the host arithmetic
+// (lut[i] = float32(float64(i) / 255.0) or float32(i)), hence the result is byte-identical to the fp32 path.
+// HBM-bound: 16 bytes in, 64 bytes out per lane.
+__global__ void __launch_bounds__(256) u8_to_f32_lut_kernel(const unsigned char* __restrict__ src,
+                                                            const float* __restrict__ lut, float* __restrict__ dst,
+                                                            long count) {
+  __shared__ float t[256];
+  t[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const long n16 = count >> 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    float4* o = reinterpret_cast<float4*>(dst) + i * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = make_float4(t[w[j] & 255u], t[(w[j] >> 8) & 255u], t[(w[j] >> 16) & 255u], t[w[j] >> 24]);
+  }
+  if (blockIdx.x == 0)  // ragged tail (counts that are not multiples of 16)
+    for (long i = (n16 << 4) + threadIdx.x; i < count; i += blockDim.x) dst[i] = t[src[i]];
+}
+
 extern "C" {
+
+int fn2_u8_to_f32_lut(const unsigned char* src, const float* lut256, float* dst, long count, void* stream) {
+  FN2_REQUIRE(src && lut256 && dst && count >= 0, "u8_to_f32_lut: null pointer / negative count");
+  FN2_REQUIRE(((size_t)src & 15) == 0 && ((size_t)dst & 15) == 0, "u8_to_f32_lut: src and dst must be 16-byte aligned");
+  if (count == 0) return FN2_OK;
+  hipLaunchKernelGGL(u8_to_f32_lut_kernel, dim3(grid_for(count >> 4, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     lut256, dst, count);
+  FN2_CHECK_LAUNCH("u8_to_f32_lut");
+  return FN2_OK;
+}
 
 int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out, int pad, void* stream) {
   FN2_REQUIRE(a && b && flow, "stack_input: null pointer");

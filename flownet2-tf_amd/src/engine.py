@@ -56,8 +56,11 @@ def _round_up(x, m):
 
 class Engine:
     def __init__(self, model, weights, batch, height, width, dtype="f32", device=None, heads_as_gemm=True,
-                 no_deconv_biases=None, strict=True):
-        """no_deconv_biases: FlowNetS_interp's constructor flag (flownet_s_interp.py:12-14); None = what the weights say
+                 no_deconv_biases=None, strict=True, uint8_inputs=False):
+        """uint8_inputs: the plan starts with two table look-up passes that turn uint8 image bytes (set_inputs_u8) into
+        the fp32 [0,1] images -- Net.adapt_x's `/ 255.0` (net.py:338-345) after the host-to-device copy instead of
+        before it, byte-identical, a quarter of the bytes over the host link.
+        no_deconv_biases: FlowNetS_interp's constructor flag (flownet_s_interp.py:12-14); None = what the weights say
         (no ``FlowNetS/predict_flow6/biases`` entry -> True).  strict: a variable under the model's scopes that no
         layer consumes raises ValueError (optimizer slots and biases the reference graph does not declare excepted:
         its Saver restores graph variables only, so those are ignored -- with a warning -- as the reference ignores them)."""
@@ -84,8 +87,24 @@ class Engine:
         self.keep = []     # keep ctypes structs / tensors alive
         self.bufs = {}
         self.layer_flops = []  # (name, flop) algorithmic, for roofline accounting
+        self.layer_bytes = []  # (name, bytes) algorithmic HBM bytes of the HBM-bound ops
         self.in_a = torch.zeros((self.N, self.H, self.W, 3), dtype=torch.float32, device=self.device)
         self.in_b = torch.zeros_like(self.in_a)
+        self.uint8_inputs = bool(uint8_inputs)
+        if self.uint8_inputs:
+            self.in_a_u8 = torch.zeros((self.N, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
+            self.in_b_u8 = torch.zeros_like(self.in_a_u8)
+            # lut[i] = float32(float64(i) / 255.0): exactly the host arithmetic of adapt_x; or float32(i) for an image
+            # whose max is <= 1 (adapt_x leaves it as it is).  One table per image, rewritten only when its mode changes
+            self._lut_div = torch.from_numpy((np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)).to(self.device)
+            self._lut_raw = torch.arange(256, dtype=torch.float32, device=self.device)
+            self._lut = [self._lut_div.clone(), self._lut_div.clone()]
+            self._lut_mode = [True, True]
+            cnt = self.in_a_u8.numel()
+            for src, lut, dst, nm in ((self.in_a_u8, self._lut[0], self.in_a, "a"), (self.in_b_u8, self._lut[1], self.in_b, "b")):
+                self.kernel_of.append("u8_to_f32_lut_kernel")
+                self.ops.append((f"input_{nm}/u8_to_f32", self.lib.fn2_u8_to_f32_lut,
+                                 (_hip.ptr(src), _hip.ptr(lut), _hip.ptr(dst), cnt)))
         self.graph = None
         self.conv_descs = []
         self.layers = []   # one record per parameterised layer, in forward order (used by the trainer)
@@ -461,6 +480,9 @@ class Engine:
         self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
                  _hip.ACT_LEAKY, kernel=f"corr2_kernel<{tn}, {tn}, {4 if self.dtype_name in ('bf16', 'f16') else 8}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
         self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
+        # a and b read once, the 441 displacement channels written once, in the reference's fp32 terms
+        # (11.71 MB per sample at 48 x 64)
+        self.layer_bytes.append((f"{tag}/correlation", 4.0 * N * (H // 8) * (W_ // 8) * (2 * 256 + 441)))
         self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
         self._conv(scope, L["conv3_1"], (net, 0, 473), (cats[3], 0, 256))
         c6_1 = self._encoder_tail(scope, tag, L, cats)
@@ -574,6 +596,23 @@ class Engine:
             if tuple(t.shape) != tuple(dst.shape):
                 raise ValueError("input shape %s != engine shape %s" % (tuple(t.shape), tuple(dst.shape)))
             dst.copy_(t.to(dtype=torch.float32), non_blocking=True)
+
+    def set_inputs_u8(self, input_a, input_b, scale=(True, True)):
+        """uint8 [N,H,W,3] images (host -- ideally pinned -- or device, torch or numpy), already zero-padded to the engine
+        size.  scale[i]: divide image i by 255 (adapt_x does when the image's max exceeds 1, net.py:338-345); the
+        conversion itself is the first two launches of the plan."""
+        if not self.uint8_inputs:
+            raise ValueError("engine was built without uint8_inputs=True")
+        for i, (dst, src) in enumerate(((self.in_a_u8, input_a), (self.in_b_u8, input_b))):
+            t = src if isinstance(src, torch.Tensor) else torch.as_tensor(src)
+            if t.dtype != torch.uint8:
+                raise ValueError("set_inputs_u8 takes uint8 images, got %s" % t.dtype)
+            if tuple(t.shape) != tuple(dst.shape):
+                raise ValueError("input shape %s != engine shape %s" % (tuple(t.shape), tuple(dst.shape)))
+            dst.copy_(t, non_blocking=True)
+            if bool(scale[i]) != self._lut_mode[i]:
+                self._lut[i].copy_(self._lut_div if scale[i] else self._lut_raw)
+                self._lut_mode[i] = bool(scale[i])
 
     def set_inputs_interp(self, input_a, matches_a, sparse_flow):
         """FlowNetS_interp input (flownet_s_interp.py:34-38): [image (3) | 0.05 * sparse_flow (2) | matches (1)]."""

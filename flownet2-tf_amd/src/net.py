@@ -66,13 +66,13 @@ class Net(object):
     def _init_weights(self, seed):
         return W.init_weights(self.model_name, seed)
 
-    def engine(self, batch, height, width):
+    def engine(self, batch, height, width, uint8_inputs=False):
         if self.weights is None:
             self.load_weights()
-        key = (batch, height, width, self.dtype)
+        key = (batch, height, width, self.dtype, bool(uint8_inputs))
         if key not in self._engines:
             self._engines[key] = Engine(self.model_name, self.weights, batch, height, width, self.dtype,
-                                        **self._engine_kwargs())
+                                        uint8_inputs=uint8_inputs, **self._engine_kwargs())
         return self._engines[key]
 
     def _engine_kwargs(self):
@@ -85,8 +85,16 @@ class Net(object):
         fp32 ROCm tensors."""
         a, b = inputs['input_a'], inputs['input_b']
         n, h, w, _ = a.shape
-        eng = self.engine(int(n), int(h), int(w))
-        out = eng(a, b)
+        if _is_u8(a) and _is_u8(b):
+            # un-normalised uint8 frames (adapt_x_u8): the bytes go to the device as they are and the `/ 255.0` of
+            # adapt_x (net.py:338-345) runs there -- byte-identical, a quarter of the host-link traffic
+            eng = self.engine(int(n), int(h), int(w), uint8_inputs=True)
+            eng.set_inputs_u8(a, b, scale=inputs.get('scale', (int(a.max()) > 1, int(b.max()) > 1)))
+            eng.launch()
+            out = eng.outputs
+        else:
+            eng = self.engine(int(n), int(h), int(w))
+            out = eng(a, b)
         return {k: v.clone() for k, v in out.items()}
 
     # ---- test-time input adaptation ---------------------------------------------------------------
@@ -114,6 +122,28 @@ class Net(object):
             pad = [(0, 0), (0, nh - h), (0, nw - w), (0, 0)]
             a, b = np.pad(a, pad), np.pad(b, pad)
         return a.astype(np.float32), b.astype(np.float32), info
+
+    def adapt_x_u8(self, input_a, input_b, divisor=64):
+        """adapt_x for uint8 frames without leaving uint8: batch axis + zero padding on the host, and the decision
+        adapt_x takes per image (`max() > 1.0` -> divide by 255, net.py:338-345) returned as `scale` for the device to
+        apply.  Returns (a_u8, b_u8, original_shape_or_None, (scale_a, scale_b))."""
+        a, b = np.asarray(input_a), np.asarray(input_b)
+        if a.dtype != np.uint8 or b.dtype != np.uint8:
+            raise ValueError("adapt_x_u8 takes uint8 images")
+        if a.shape != b.shape:
+            raise AssertionError("FATAL: image dimensions do not match. Image 1 has shape: {0}, "
+                                 "Image 2 has shape: {1}".format(a.shape, b.shape))
+        scale = (bool(a.max() > 1), bool(b.max() > 1))
+        if a.ndim == 3:
+            a, b = a[None], b[None]
+        h, w = a.shape[1:3]
+        nh, nw = self.get_padded_image_size(h, w, divisor)
+        info = None
+        if (nh, nw) != (h, w):
+            info = a.shape
+            pad = [(0, 0), (0, nh - h), (0, nw - w), (0, 0)]
+            a, b = np.pad(a, pad), np.pad(b, pad)
+        return np.ascontiguousarray(a), np.ascontiguousarray(b), info, scale
 
     def adapt_x_matches(self, input_a, matches_a, sparse_flow, divisor=64):
         """adapt_x for (image, match mask, sparse flow) (net.py:324-392): image and mask to [0,1] when their max
@@ -154,8 +184,9 @@ class Net(object):
                                                   read_flow(sparse_flow_path))
             preds = self.model({'input_a': a, 'matches_a': m, 'sparse_flow': sf}, LONG_SCHEDULE, trainable=False)
         else:
-            a, b, info = self.adapt_x(imread(input_a_path), imread(input_b_path))
-            preds = self.model({'input_a': a, 'input_b': b}, LONG_SCHEDULE, trainable=False)
+            # image files decode to uint8: they cross the host link as bytes and are normalised on the device
+            a, b, info, scale = self.adapt_x_u8(imread(input_a_path), imread(input_b_path))
+            preds = self.model({'input_a': a, 'input_b': b, 'scale': scale}, LONG_SCHEDULE, trainable=False)
         flow = preds['flow'][0].float().cpu().numpy()
         y_info = (info[-3], info[-2], 2) if info is not None else None
         flow = self.postproc_y_hat_test(flow, y_info)
@@ -263,18 +294,21 @@ class Net(object):
     def _infer_pairs(self, chunk, batch_size):
         """Flows (cropped to each frame's size) of up to `batch_size` list lines, one engine launch per group of
         equally sized frames; a short group is padded with zero pairs so that one engine serves the whole list."""
-        frames = [self.adapt_x(imread(p[0]), imread(p[1])) for p in chunk]
+        frames = [self.adapt_x_u8(imread(p[0]), imread(p[1])) for p in chunk]
         out = [None] * len(chunk)
         by_shape = {}
-        for i, (a, _, _) in enumerate(frames):
-            by_shape.setdefault(a.shape, []).append(i)
-        for shape, idxs in by_shape.items():
+        for i, (a, _, _, scale) in enumerate(frames):
+            by_shape.setdefault((a.shape, scale), []).append(i)  # one normalisation decision per launch
+        for (shape, scale), idxs in by_shape.items():
             n = batch_size
-            a = np.zeros((n,) + shape[1:], np.float32)
+            a = np.zeros((n,) + shape[1:], np.uint8)
             b = np.zeros_like(a)
             for j, i in enumerate(idxs):
                 a[j], b[j] = frames[i][0][0], frames[i][1][0]
-            pred = self.engine(n, shape[1], shape[2])(a, b)['flow'].float().cpu().numpy()
+            eng = self.engine(n, shape[1], shape[2], uint8_inputs=True)
+            eng.set_inputs_u8(a, b, scale)
+            eng.launch()
+            pred = eng.outputs['flow'].float().cpu().numpy()
             for j, i in enumerate(idxs):
                 info = frames[i][2]
                 out[i] = self.postproc_y_hat_test(pred[j], (info[-3], info[-2], 2) if info is not None else None).copy()
@@ -300,6 +334,10 @@ class Net(object):
         if empty0 > 0:
             avg[9] = avg[9] * (divisor[9] / (divisor[9] - empty0))
         return avg
+
+
+def _is_u8(x):
+    return (isinstance(x, np.ndarray) and x.dtype == np.uint8) or (isinstance(x, torch.Tensor) and x.dtype == torch.uint8)
 
 
 def imread_gray(path):

@@ -188,6 +188,13 @@ int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out
 int fn2_upsample_flow(const float* in, const float* w, const float* bias, const fn2_tensor* out, int n, int h, int wd,
                       void* stream);
 
+/* uint8 image bytes -> fp32 [0,1] after the host-to-device copy: replaces the host side of Net.adapt_x's
+ * normalisation (src/net.py:338-345: `x / 255.0` when the image's max exceeds 1) so that images cross PCIe as one
+ * byte per channel.  dst[i] = lut256[src[i]]; the caller supplies the table (float32(float64(i) / 255.0), or
+ * float32(i) for an image whose max is <= 1), which makes the result byte-identical to the host arithmetic.
+ * src, dst: device, 16-byte aligned; count = number of bytes. */
+int fn2_u8_to_f32_lut(const unsigned char* src, const float* lut256, float* dst, long count, void* stream);
+
 /* The four "network input" builders below write the INTERIOR of a view whose h, w include a zero border of
  * `pad` pixels on every side (allocated zero by the caller, never written): the reference's pad() in front
  * of the stem convolution (utils.py:408-412) is baked into the buffer, so the stem can run as a kind-2

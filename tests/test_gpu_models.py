@@ -381,3 +381,51 @@ def test_sample_pair_against_the_committed_fixture(golden_dir, dtype):
     flow = out["flow"].float().cpu().numpy()
     assert np.sqrt(((pf6 - g["predict_flow6"]) ** 2).sum(-1)).mean() < 1e-3
     assert np.sqrt(((flow[0, g["probe_y"], g["probe_x"]] - g["flow_probes"]) ** 2).sum(-1)).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_uint8_input_path_is_byte_identical_to_the_fp32_path():
+    """Net.adapt_x (net.py:338-392) divides uint8 frames by 255 on the host and ships float32; the uint8 path ships the
+    bytes and divides on the device through a table holding the host arithmetic.  Same flow, bit for bit -- through
+    the engine, through Net.model, graph replay included; an image whose max is <= 1 is left undivided as adapt_x does."""
+    import ctypes as C
+    from src import _hip, weights as W
+    from src.engine import Engine
+    from src.flownet_c.flownet_c import FlowNetC
+    from src.net import Mode
+    rng = np.random.default_rng(21)
+    a8 = rng.integers(0, 256, (436, 500, 3)).astype(np.uint8)
+    b8 = np.roll(a8, (2, -3), (0, 1))
+    net = FlowNetC(mode=Mode.TEST, dtype="f16x2")
+    wts = net.load_weights(None, seed=5)
+    af, bf, info = net.adapt_x(a8, b8)
+    au, bu, info_u, scale = net.adapt_x_u8(a8, b8)
+    assert info == info_u == (1, 436, 500, 3) and scale == (True, True) and au.shape == (1, 448, 512, 3) and au.dtype == np.uint8
+    want = net.model({"input_a": af, "input_b": bf})["flow"]
+    got = net.model({"input_a": au, "input_b": bu, "scale": scale})["flow"]
+    assert torch.equal(got, want)
+    eng = net.engine(1, 448, 512, uint8_inputs=True)
+    assert torch.equal(eng.in_a, torch.from_numpy(af).cuda()) and torch.equal(eng.in_b, torch.from_numpy(bf).cuda())
+    eng.capture()
+    eng.set_inputs_u8(bu, au)            # other inputs through the captured plan ...
+    eng.launch()
+    eng.set_inputs_u8(au, bu)            # ... and back
+    eng.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.outputs["flow"], want)
+    # an image of zeros and ones: max <= 1, adapt_x leaves it as it is (no division)
+    ones = (rng.random((64, 64, 3)) < 0.5).astype(np.uint8)
+    f1, f2, _ = net.adapt_x(ones, ones)
+    u1, u2, _, sc = net.adapt_x_u8(ones, ones)
+    assert sc == (False, False) and f1.max() == 1.0
+    assert torch.equal(net.model({"input_a": u1, "input_b": u2, "scale": sc})["flow"],
+                       net.model({"input_a": f1, "input_b": f2})["flow"])
+    # the C entry point on a ragged count
+    lib = _hip.lib()
+    src = torch.from_numpy(rng.integers(0, 256, 1000003).astype(np.uint8)).cuda()
+    lut = torch.from_numpy((np.arange(256) / 255.0).astype(np.float32)).cuda()
+    dst = torch.full((1000003,), -1.0, device="cuda")
+    _hip.check(lib.fn2_u8_to_f32_lut(_hip.ptr(src), _hip.ptr(lut), _hip.ptr(dst), 1000003, _hip.stream_ptr()))
+    assert np.array_equal(dst.cpu().numpy(), (src.cpu().numpy() / 255.0).astype(np.float32))
+    with pytest.raises(ValueError):
+        Engine("FlowNetC", wts, 1, 64, 64, "f32").set_inputs_u8(u1, u2)
