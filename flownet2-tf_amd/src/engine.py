@@ -84,6 +84,27 @@ class Engine:
         self.ignored_variables = []     # biases present in `weights` that the reference graph does not declare
         self.ops = []      # (name, fn, args) ; args exclude the trailing stream
         self.kernel_of = []  # per op: the device kernel (template instantiation) that does the work
+        # Lanes: launches that do not depend on each other are tagged with different lanes; capture() records every
+        # lane on its own stream, so the hipGraph holds them as parallel paths and their launches fill the CUs that the
+        # other paths' small grids, tails and launch gaps leave idle.  Lane 0: the main chain; 1: FlowNetSD beside the
+        # C -> S -> S chain (flownet2.py:22-23); 2 / 3: the flow-head chain (predict_flowN -> upsample_flow, a few
+        # blocks per launch) beside the transposed convs of lane 0 / 1; 4: FlowNetC's second tower.  self.syncs holds
+        # (op index, waiter, waited): before op #index is issued, lane `waiter` waits for everything issued on lane
+        # `waited` so far.  The list order is a valid sequential order: eager launches ignore lanes and syncs.
+        # Scratch (split-K workspace, head GEMM partials) is per lane.  FN2_BRANCHES=0: everything on lane 0.
+        self.branch_of = []
+        self._branch = 0
+        self.desc_branch = []
+        self.syncs = []
+        self._lanes_on = bool(int(os.environ.get("FN2_BRANCHES", "1")))
+        # bit b: lane b enabled (else its launches stay on the parent lane).  Measured (tools/ab_branches.py, same
+        # process, interleaved): FlowNet2 b4 5.00 ms without lanes, 4.57 with lane 1, 4.54 with lanes 1 + 4 -- but 4.98
+        # with the head lane 2 added (every cross-lane edge of the graph costs a few microseconds of queue hand-off:
+        # fine-grained fork/joins eat what two long independent chains gain), and lane 3 (cross-waits between two
+        # forked streams, neither of them the capture's origin) crashes hipStreamEndCapture on ROCm 7.2.  FlowNetC b8
+        # alone: 1.641 -> 1.597 with lanes 2 + 4.
+        default_mask = 0b10011 if model == "FlowNet2" else 0b10101
+        self._lane_mask = int(os.environ.get("FN2_LANE_MASK", str(default_mask)))
         self.keep = []     # keep ctypes structs / tensors alive
         self.bufs = {}
         self.layer_flops = []  # (name, flop) algorithmic, for roofline accounting
@@ -105,6 +126,7 @@ class Engine:
                 self.kernel_of.append("u8_to_f32_lut_kernel")
                 self.ops.append((f"input_{nm}/u8_to_f32", self.lib.fn2_u8_to_f32_lut,
                                  (_hip.ptr(src), _hip.ptr(lut), _hip.ptr(dst), cnt)))
+                self.branch_of.append(0)
         self.graph = None
         self.conv_descs = []
         self.layers = []   # one record per parameterised layer, in forward order (used by the trainer)
@@ -183,9 +205,31 @@ class Engine:
                              "ignore them" % (self.model, len(stray), ", ".join(sorted(stray)[:4])))
         self.stray_variables = stray
 
+    def _sync(self, waiter, waited):
+        if waiter != waited:
+            self.syncs.append((len(self.ops), waiter, waited))
+
+    def _lane(self, lane):
+        """Context manager: the launches added inside go to `lane` (lane 0 when lanes are disabled)."""
+        eng = self
+
+        class _L:
+            def __enter__(self_):
+                self_.prev = eng._branch
+                eng._branch = lane if (eng._lanes_on and (eng._lane_mask >> lane) & 1) else self_.prev
+
+            def __exit__(self_, *exc):
+                eng._branch = self_.prev
+        return _L()
+
+    def _head_lane(self):
+        hd = self._branch + 2
+        return hd if (self._lanes_on and self._branch in (0, 1) and (self._lane_mask >> hd) & 1) else self._branch
+
     def _op(self, name, fn, *args, kernel=None):
         self.kernel_of.append(kernel if kernel is not None else fn.__name__.replace("fn2_", ""))
         self.ops.append((name, fn, args))
+        self.branch_of.append(self._branch)
 
     # ------------------------------------------------------------------ layers
     def _conv(self, scope, spec, src, dst):
@@ -240,6 +284,7 @@ class Engine:
         d.out_scale = out_scale
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
+        self.desc_branch.append(self._branch)
         self.layers.append(dict(scope=scope, name=name, kind=d.kind, k=k, stride=stride, pad=pad, cin=cin, cout=cout,
                                 act=bool(act), src=src, dst=dst, desc=d, w=wdev, b=bias, cin_pad=cin_pad,
                                 cout_pad=cout_pad, kpad=kpad, layout=layout, tile=tile, kstep=plan.kstep_elems))
@@ -284,12 +329,15 @@ class Engine:
                 packed, out_scale = packed * (2.0 ** k2), 2.0 ** (-k2)
         wdev = W.packed_to_device(packed, plan.wgt_dtype, self.device)
         bias = self._bias(scope, name, kind, cout)
-        if self._head_t is None:  # one scratch for every head: launches are ordered on one stream
-            self._head_t = torch.zeros((self.N * self.H * self.W, 32), dtype=torch.float32, device=self.device)
+        if self._head_t is None:
+            self._head_t = {}
+        if self._branch not in self._head_t:  # one scratch for every head of a branch: its launches are ordered
+            self._head_t[self._branch] = torch.zeros((self.N * self.H * self.W, 32), dtype=torch.float32, device=self.device)
+        head_t = self._head_t[self._branch]
         n, h, wd = pf.shape[0], pf.shape[1], pf.shape[2]
         d = _hip.Fn2ConvDesc()
         d.inp = self._v(sbuf, sc, sc0)
-        d.out = _hip.Fn2Tensor(self._head_t.data_ptr(), _hip.FN2_F32, n, h, wd, 18, 32, 0)
+        d.out = _hip.Fn2Tensor(head_t.data_ptr(), _hip.FN2_F32, n, h, wd, 18, 32, 0)
         d.wgt, d.bias = wdev.data_ptr(), None
         d.kind, d.kh, d.kw, d.stride, d.pad = 0, 1, 1, 1, 0
         d.act = _hip.ACT_NONE
@@ -297,10 +345,11 @@ class Engine:
         d.out_scale = out_scale
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
+        self.desc_branch.append(self._branch)
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
                  kernel=f"conv_igemm2_kernel<{tn}, float, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1)}>")
-        self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(self._head_t), 32,
+        self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(head_t), 32,
                  _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd)
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
         return True
@@ -350,6 +399,7 @@ class Engine:
         d.out_scale = out_scale
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
+        self.desc_branch.append(self._branch)
         self.layers.append(dict(scope=scope, name=name, kind=2, k=k, stride=stride, pad=pad, cin=cin, cout=cout,
                                 act=bool(act), src=(sbuf, 0, cs), dst=dst, desc=d, w=wdev, b=bias, cin_pad=cin_pad,
                                 cout_pad=cout_pad, kpad=kpad, layout=plan.layout, tile=plan.cout_tile,
@@ -379,39 +429,60 @@ class Engine:
         return dst
 
     def _alloc_workspace(self):
-        """One fp32 split-K scratch buffer shared by every layer (launches are ordered on one stream)."""
-        need = max([int(self.lib.fn2_conv2d_workspace_bytes(C.byref(d))) for d in self.conv_descs] + [0])
-        self.workspace = None
-        if need > 0:
-            self.workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
-            for d in self.conv_descs:
-                d.workspace = self.workspace.data_ptr()
-                d.workspace_bytes = need
+        """One fp32 split-K scratch buffer per branch, shared by the branch's layers (its launches are ordered)."""
+        branches = self.desc_branch + [0] * (len(self.conv_descs) - len(self.desc_branch))  # the trainer appends descs
+        self.workspace = {}
+        for br in sorted(set(branches)):
+            descs = [d for d, b in zip(self.conv_descs, branches) if b == br]
+            need = max([int(self.lib.fn2_conv2d_workspace_bytes(C.byref(d))) for d in descs] + [0])
+            if need > 0:
+                self.workspace[br] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+                for d in descs:
+                    d.workspace = self.workspace[br].data_ptr()
+                    d.workspace_bytes = need
 
     # ------------------------------------------------------------------ sub-networks
     def _refine(self, scope, tag, L, c6_1, cats, interconv):
-        """4-level decoder (flownet_s.py:52-104; flownet_sd.py:45-103)."""
+        """4-level decoder (flownet_s.py:52-104; flownet_sd.py:45-103).  The flow-head chain (predict_flowN ->
+        upsample_flow, launches of a few blocks) runs on the head lane beside the transposed conv of the same level."""
         N = c6_1.shape[0]
         preds = {}
+        M, Hd = self._branch, self._head_lane()
         h, w = c6_1.shape[1], c6_1.shape[2]
         pf = self._buf(f"{tag}/predict_flow6", N, h, w, 2, torch.float32)
-        self._conv(scope, L["predict_flow6"], (c6_1, 0, 1024), (pf, 0, 2))
+        self._sync(Hd, M)  # conv6_1 is there
+        with self._lane(Hd):
+            self._conv(scope, L["predict_flow6"], (c6_1, 0, 1024), (pf, 0, 2))
         preds["predict_flow6"] = pf
         cur, cur_c = c6_1, 1024
         for lvl, skip_c, dec_c in zip((5, 4, 3, 2), (512, 512, 256, 128), (512, 256, 128, 64)):
             cat = cats[lvl]
             h, w = cat.shape[1], cat.shape[2]
             self._conv(scope, L[f"deconv{lvl}"], (cur, 0, cur_c), (cat, skip_c, dec_c))
-            self._upflow(scope, f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2))
+            with self._lane(Hd):
+                self._upflow(scope, f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2))
+            self._sync(M, Hd)  # concat complete for the main lane's readers (next deconv / interconv)
+            if not interconv:
+                self._sync(Hd, M)  # ... and for the head (with an interconv the head waits for that instead)
             cur, cur_c = cat, skip_c + dec_c + 2
             head_src = (cat, 0, cur_c)
             if interconv:
                 ic = self._buf(f"{tag}/interconv{lvl}", N, h, w, dec_c)
                 self._conv(scope, L[f"interconv{lvl}"], (cat, 0, cur_c), (ic, 0, dec_c))
+                self._sync(Hd, M)
                 head_src = (ic, 0, dec_c)
             pf = self._buf(f"{tag}/predict_flow{lvl}", N, h, w, 2, torch.float32)
-            self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2))
+            with self._lane(Hd):
+                self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2))
             preds[f"predict_flow{lvl}"] = pf
+        return preds
+
+    def _final_flow(self, tag, preds, scale):
+        """flow = resize_bilinear(scale * predict_flow2) on the head lane; the main lane then waits for it."""
+        M, Hd = self._branch, self._head_lane()
+        with self._lane(Hd):
+            preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], scale)
+        self._sync(M, Hd)
         return preds
 
     def _alloc_cats(self, tag, N):
@@ -449,8 +520,7 @@ class Engine:
         self._conv(scope, L["conv3_1"], (c3, 0, 256), (cats[3], 0, 256))
         c6_1 = self._encoder_tail(scope, tag, L, cats)
         preds = self._refine(scope, tag, L, c6_1, cats, False)
-        preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], 20.0)  # flownet_s.py:107-111
-        return preds
+        return self._final_flow(tag, preds, 20.0)  # flownet_s.py:107-111
 
     def _net_c(self, scope, tag):
         """FlowNetC.model (flownet_c.py:15-125).  conv1 of both towers is one 2N-batch launch."""
@@ -467,12 +537,18 @@ class Engine:
         c1 = self._buf(f"{tag}/conv1", 2 * N, H // 2, W_ // 2, 64)
         self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64), s2d=True)
         c2b = self._buf(f"{tag}/conv_b_2", N, H // 4, W_ // 4, 128)
+        M, T = self._branch, (4 if (self._lanes_on and self._lane_mask & 16) else self._branch)  # second tower (and conv_redir) on lane 4
+        self._sync(T, M)
         self._conv(scope, L["conv2"], (c1[:N], 0, 64), (cats[2], 0, 128))  # conv_a_2 = the level-2 skip, :105
-        self._conv(scope, L["conv2"], (c1[N:], 0, 64), (c2b, 0, 128))
+        with self._lane(T):
+            self._conv(scope, L["conv2"], (c1[N:], 0, 64), (c2b, 0, 128))
         c3a = self._buf(f"{tag}/conv_a_3", N, H // 8, W_ // 8, 256)
         c3b = self._buf(f"{tag}/conv_b_3", N, H // 8, W_ // 8, 256)
         self._conv(scope, L["conv3"], (cats[2], 0, 128), (c3a, 0, 256))
-        self._conv(scope, L["conv3"], (c2b, 0, 128), (c3b, 0, 256))
+        with self._lane(T):
+            self._conv(scope, L["conv3"], (c2b, 0, 128), (c3b, 0, 256))
+        self._sync(M, T)  # the correlation reads both towers
+        self._sync(T, M)  # conv_redir (lane T, beside the correlation) reads conv_a_3
         net = self._buf(f"{tag}/corr_concat", N, H // 8, W_ // 8, 473)  # [conv_redir(32) | corr(441)], :46
         va, vb, vo = self._v(c3a, 256, 0), self._v(c3b, 256, 0), self._v(net, 441, 32)
         self.keep += [va, vb, vo]
@@ -483,12 +559,13 @@ class Engine:
         # a and b read once, the 441 displacement channels written once, in the reference's fp32 terms
         # (11.71 MB per sample at 48 x 64)
         self.layer_bytes.append((f"{tag}/correlation", 4.0 * N * (H // 8) * (W_ // 8) * (2 * 256 + 441)))
-        self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
+        with self._lane(T):
+            self._conv(scope, L["conv_redir"], (c3a, 0, 256), (net, 0, 32))
+        self._sync(M, T)
         self._conv(scope, L["conv3_1"], (net, 0, 473), (cats[3], 0, 256))
         c6_1 = self._encoder_tail(scope, tag, L, cats)
         preds = self._refine(scope, tag, L, c6_1, cats, False)
-        preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], 20.0)  # flownet_c.py:112-116
-        return preds
+        return self._final_flow(tag, preds, 20.0)  # flownet_c.py:112-116
 
     def _net_sd(self, scope, tag, x):
         """FlowNetSD.model (flownet_sd.py:14-119)."""
@@ -509,8 +586,7 @@ class Engine:
         self._conv(scope, L["conv3_1"], (c3, 0, 256), (cats[3], 0, 256))
         c6_1 = self._encoder_tail(scope, tag, L, cats)
         preds = self._refine(scope, tag, L, c6_1, cats, True)
-        preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], 0.05)  # flownet_sd.py:106-110
-        return preds
+        return self._final_flow(tag, preds, 0.05)  # flownet_sd.py:106-110
 
     def _pair_input(self, tag, pad):
         """[a | b] with the stem's zero border of `pad` pixels baked in (flownet_s.py:24,39)."""
@@ -539,8 +615,18 @@ class Engine:
     def _net_2(self, scope, tag):
         """FlowNet2.model (flownet2.py:18-105)."""
         N, H, W_ = self.N, self.H, self.W
+        fork = len(self.ops)  # FlowNetSD (lane 1) depends on nothing but the images: it forks here, in front of the chain
         css = self._net_css(scope + "/FlowNetCSS", tag + "/CSS")
-        sd = self._net_sd(scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD", 1))
+        if self._lanes_on and self._lane_mask & 2:
+            self.syncs.append((fork, 1, 0))
+            if self._lane_mask & 8 and int(os.environ.get("FN2_FORK3", "1")):
+                # the SD head lane forks from the capture's origin stream as well: a stream that first enters the
+                # capture by waiting on ANOTHER forked stream crashed hipStreamEndCapture / hipGraphInstantiate (ROCm 7.2)
+                self.syncs.append((fork, 3, 0))
+        with self._lane(1):
+            sd = self._net_sd(scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD", 1))
+        if self._lanes_on and self._lane_mask & 2:
+            self._sync(0, 1)
         L = {s[0]: s for s in netdefs.fusion_layers()}
         xf = self._buf(f"{tag}/fusion_in", N, H + 2, W_ + 2, 16, stem=True)
         v = self._v(xf, 11, 0)
@@ -558,15 +644,24 @@ class Engine:
         f2_1 = self._buf(f"{tag}/fuse_conv2_1", N, H // 4, W_ // 4, 128)
         self._conv(scope, L["fuse_conv2_1"], (f2, 0, 128), (f2_1, 0, 128))
         pf2 = self._buf(f"{tag}/predict_flow2", N, H // 4, W_ // 4, 2, torch.float32)
-        self._conv(scope, L["predict_flow2"], (f2_1, 0, 128), (pf2, 0, 2))
+        M, Hd = self._branch, self._head_lane()
+        self._sync(Hd, M)
+        with self._lane(Hd):  # head + upsample beside the transposed conv, as in _refine
+            self._conv(scope, L["predict_flow2"], (f2_1, 0, 128), (pf2, 0, 2))
         self._conv(scope, L["fuse_deconv1"], (f2_1, 0, 128), (cat1, 128, 32))
-        self._upflow(scope, "fuse_upsample_flow2to1", pf2, (cat1, 160, 2))
+        with self._lane(Hd):
+            self._upflow(scope, "fuse_upsample_flow2to1", pf2, (cat1, 160, 2))
+        self._sync(M, Hd)
         ic1 = self._buf(f"{tag}/fuse_interconv1", N, H // 2, W_ // 2, 32)
         self._conv(scope, L["fuse_interconv1"], (cat1, 0, 162), (ic1, 0, 32))
+        self._sync(Hd, M)
         pf1 = self._buf(f"{tag}/predict_flow1", N, H // 2, W_ // 2, 2, torch.float32)
-        self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2))
+        with self._lane(Hd):
+            self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2))
         self._conv(scope, L["fuse_deconv0"], (cat1, 0, 162), (cat0, 64, 16))
-        self._upflow(scope, "fuse_upsample_flow1to0", pf1, (cat0, 80, 2))
+        with self._lane(Hd):
+            self._upflow(scope, "fuse_upsample_flow1to0", pf1, (cat0, 80, 2))
+        self._sync(M, Hd)
         ic0 = self._buf(f"{tag}/fuse_interconv0", N, H, W_, 16)
         self._conv(scope, L["fuse_interconv0"], (cat0, 0, 82), (ic0, 0, 16))
         pf0 = self._buf(f"{tag}/predict_flow0", N, H, W_, 2, torch.float32)
@@ -643,18 +738,53 @@ class Engine:
             return
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
+        extra = {b: torch.cuda.Stream(device=self.device) for b in sorted(set(self.branch_of) - {0})}
         with torch.cuda.stream(side):
             self.launch()  # warm: module load, first-touch
             side.synchronize()
             _hip.check(self.lib.fn2_capture_begin(_hip.stream_ptr()))
             try:
-                self.launch()
+                if not extra:
+                    self.launch()
+                else:
+                    self._launch_branches(side, extra)
             finally:
                 g = C.c_void_p()
                 rc = self.lib.fn2_capture_end(_hip.stream_ptr(), C.byref(g))
             _hip.check(rc)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = g
+        self._capture_streams = (side, extra)
+
+    def _launch_branches(self, main, extra):
+        """Issue the plan with lane b > 0 on its own stream (inside a stream capture: parallel paths of the graph),
+        applying self.syncs; every lane is joined back into `main` at the end."""
+        streams = dict(extra)
+        streams[0] = main
+        events = []  # kept alive until the capture has ended (an event destroyed while its record node is being captured
+        #              is not something to rely on)
+
+        def wait(waiter, waited):
+            ev = torch.cuda.Event()
+            ev.record(streams[waited])
+            streams[waiter].wait_event(ev)
+            events.append(ev)
+
+        self._capture_events = events
+        by_index = {}
+        for idx, waiter, waited in self.syncs:
+            by_index.setdefault(idx, []).append((waiter, waited))
+        for i, ((name, fn, args), br) in enumerate(zip(self.ops, self.branch_of)):
+            for waiter, waited in by_index.get(i, ()):
+                wait(waiter, waited)
+            rc = fn(*args, streams[br].cuda_stream)
+            if rc:
+                try:
+                    _hip.check(rc)
+                except Exception as e:
+                    raise type(e)("%s: %s" % (name, e)) from None
+        for b in extra:
+            wait(0, b)
 
     def __call__(self, input_a, input_b):
         self.set_inputs(input_a, input_b)
