@@ -800,7 +800,26 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   // two stages of DMA in flight instead of one (+4..7 %; with a third resident block to lose it is 5-12 % slower).
   // FN2_RING_MAX = largest such grid (0 = never); FN2_CONV_DBG bit 256 = ring on every 128 x 64 layer (A/B).
   // (the same rule on the 64- and 32-cout tiles measured neutral: not instantiated)
-  if (d->wgt_layout == 1 && tile == 128 && a.bp64 == 1) {
+  // K groups (conv2.hip): 128-cout layers whose 128 x 64 grid is under 96 blocks -- the 6x8 / 12x16 levels, which used
+  // 128 x 128 tiles + up to 16 partial-sum slabs before -- run two groups of four waves per block (in-block split-K)
+  // and half the slabs: conv5..deconv5 10-18 % faster, FlowNet2 b4 -2 % end to end.  Measured and NOT taken: groups on
+  // the 96..256-block layers (conv4, conv4_1, deconv3/4 at batch 4).  The groups of a block share its barriers, so
+  // they issue their DMA pieces together and compute together; separate split-K blocks drift apart and overlap:
+  // conv4_1 200 -> 157 TFLOP/s, deconv4 161 -> 83 with groups instead of splits.  Three groups (144 KB of LDS) lose
+  // to two on the small levels as well.  FN2_KG=0 switches groups off (A/B); FN2_KG3_MAX / FN2_KG2_MAX = largest
+  // grids that take 3 / 2 groups.
+  a.kg = 1;
+  if (d->wgt_layout == 1 && tile == 128 && !(a.dbg & 32)) {
+    const char* e_kg = getenv("FN2_KG");
+    if (!e_kg || atoi(e_kg) != 0) {
+      const char* e3 = getenv("FN2_KG3_MAX");
+      const char* e2 = getenv("FN2_KG2_MAX");
+      const long blocks = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * phases;
+      if (blocks <= (e3 ? atoi(e3) : 0)) { a.bp64 = 1; a.kg = 3; }
+      else if (blocks <= (e2 ? atoi(e2) : 95)) { a.bp64 = 1; a.kg = 2; }
+    }
+  }
+  if (d->wgt_layout == 1 && tile == 128 && a.bp64 == 1 && a.kg == 1) {
     const char* e_ring = getenv("FN2_RING_MAX");  // tuning knob (read per launch: tools/ab_conv.py toggles it in-process)
     const int ring_max = e_ring ? atoi(e_ring) : 512;
     const long blocks = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * phases;
@@ -818,6 +837,19 @@ static int preferred_split(const ConvArgs& a, int tile, int phases) {
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
   const char* e_min = getenv("FN2_SPLIT_MINBLOCKS");  // tuning knob: grids from this many blocks up take no split-K
   if (blocks >= (e_min ? atoi(e_min) : 384)) return 1;
+  if (a.kg > 1) {
+    // K-group blocks hold a CU each (96 / 144 KB of LDS): one round = 256 blocks; a group wants >= 6 stages
+    const char* e_nos = getenv("FN2_KG_NOSPLIT");  // grids from this many blocks up take no split
+    if (blocks >= (e_nos ? atoi(e_nos) : 96)) return 1;
+    const char* e_sl = getenv("FN2_KG_SLOTS");
+    int s = (int)((e_sl ? atoi(e_sl) : 256) / blocks);
+    const int maxs = a.ksteps / (12 * a.kg);
+    if (s > maxs) s = maxs;
+    if (s > 16) s = 16;
+    if (s < 2) return 1;
+    const int kper = cdiv(a.ksteps, s);
+    return cdiv(a.ksteps, kper);
+  }
   // as many splits as still give ONE round of resident blocks (2-3 per CU): rounding up put 528 blocks on 512
   // slots for the 12x16-level layers and a second round of 16 stragglers doubled the kernel time
   const char* e = getenv("FN2_SPLIT_SLOTS");  // tuning knob of the experiments behind the default

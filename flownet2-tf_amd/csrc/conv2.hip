@@ -78,8 +78,13 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
 // STAGES = 3: a 3-slot LDS ring with the DMA TWO stages ahead, for the weight-streaming layers (6x8 / 12x16
 // levels): there every stage waits a full HBM round trip for weights nobody has touched yet, and one stage of
 // look-ahead per block leaves the chip latency-bound (conv6_1: 38 MB of weights in 46 us).
-template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2>
-__global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
+// KG = K groups: a block of KG x 4 waves in which group g runs the stages kt0 + g, kt0 + g + KG, ... of the tile on
+// its own pair of stage buffers, and the groups' accumulators are summed through LDS (fixed order) in front of the
+// epilogue -- split-K inside the workgroup.  Used on the 6x8 / 12x16 levels (grids under 96 blocks of 128 x 64), where
+// it halves the number of partial-sum slabs the split-K finalize pass has to read (policy and measurements: conv.hip,
+// build_args).
+template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2, int KG = 1>
+__global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
   constexpr int ESZ = (int)sizeof(T);
@@ -92,12 +97,17 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
   // LDS-DMA when it can prove (alias scopes of distinct LDS variables) that they touch different objects; with
   // one array and a runtime buffer index it put s_waitcnt vmcnt(0) in front of every stage's first ds_read,
   // i.e. the "prefetch" of stage s+1 was waited for BEFORE the MFMAs of stage s.
-  __shared__ uint4 lds0[ROWS * 8];
-  __shared__ uint4 lds1[ROWS * 8];
+  static_assert(KG == 1 || STAGES == 2, "K groups run the two-stage loop");
+  __shared__ uint4 lds0_all[KG * ROWS * 8];
+  __shared__ uint4 lds1_all[KG * ROWS * 8];
   __shared__ uint4 lds2[STAGES == 3 ? ROWS * 8 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KG > 1 ? wave_all >> 2 : 0;   // K group of this wave
+  const int wave = KG > 1 ? wave_all & 3 : wave_all;
+  uint4* const lds0 = lds0_all + grp * (ROWS * 8);
+  uint4* const lds1 = lds1_all + grp * (ROWS * 8);
   const int wc = wave / WP, wp = wave % WP;
 
   int pad_y = p.pad, pad_x = p.pad, oy_off = 0, ox_off = 0, osc = 1;
@@ -109,8 +119,8 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     pad_y = a ? p.ph_pad1 : p.ph_pad0; pad_x = b ? p.ph_pad1 : p.ph_pad0; oy_off = a; ox_off = b; osc = 2;
     wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
   }
-  const int kt0 = split * p.kper;
-  const int kt1 = min(p.ksteps, kt0 + p.kper);
+  const int kt0 = split * p.kper + grp;  // first stage of this K group
+  const int kt1 = min(p.ksteps, split * p.kper + p.kper);
   // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id
   // order, so with the plain mapping a pixel tile's vertical neighbours and its other cout tiles run on other
   // XCDs / much later: every 3x3 halo row and every extra cout tile re-read the activations from HBM.  Give
@@ -189,7 +199,7 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
         dma16(rsrc_x, &lds[(BC + wave * (BP / 4) + j * 8) * 8], voff, 0);
     }
   };
-  auto advance = [&]() {
+  auto advance1 = [&]() {
     ++wstage;
     if (tap_outer) {
       if (++sc == spt) {
@@ -201,6 +211,10 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       kx = 0;
       if (++ky == p.KH) { ky = 0; ++sc; }
     }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int g = 0; g < KG; ++g) advance1();  // this group's next stage
   };
   auto issue_stage = [&](uint4* lds) {
     [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -305,7 +319,8 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
     issue_stage(lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int nst2 = (kt1 - kt0 + 1) & ~1;
+    // trip count of group 0 (the longest), rounded up to even; groups that run out of stages add zero stages
+    const int nst2 = ((kt1 - (kt0 - grp) + KG - 1) / KG + 1) & ~1;
     for (int s = 0; s < nst2; s += 2) {
       issue_stage(lds1);  // next stage's DMA in flight under this stage's MFMAs
       compute(lds0);
@@ -337,6 +352,38 @@ __global__ void __launch_bounds__(256) conv_igemm2_kernel(const ConvArgs p) {
       ring_sync(); issue_stage(lds1); compute(lds2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead stages (all-zero pixel rows past kt1)
+  }
+
+  if constexpr (KG > 1) {
+    // sum the K groups through LDS (every wave is past the loop's last barrier: the stage buffers are free), group 1
+    // first, then group 2: a fixed order, so the result does not depend on timing
+    constexpr int NA4 = TCN * TPN * 4;
+    static_assert((KG - 1) * 4 * NA4 * 64 <= KG * ROWS * 8, "reduction scratch must fit the stage buffers");
+    float4* red = reinterpret_cast<float4*>(lds0_all);
+    if (grp > 0) {
+#pragma unroll
+      for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TPN; ++tp)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            red[(((grp - 1) * 4 + wave) * NA4 + (tc * TPN + tp) * 4 + q) * 64 + lane] =
+                make_float4(acc[tc][tp][4 * q], acc[tc][tp][4 * q + 1], acc[tc][tp][4 * q + 2], acc[tc][tp][4 * q + 3]);
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 0; g < KG - 1; ++g)
+#pragma unroll
+      for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TPN; ++tp)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = red[((g * 4 + wave) * NA4 + (tc * TPN + tp) * 4 + q) * 64 + lane];
+            acc[tc][tp][4 * q] += v.x; acc[tc][tp][4 * q + 1] += v.y;
+            acc[tc][tp][4 * q + 2] += v.z; acc[tc][tp][4 * q + 3] += v.w;
+          }
   }
 
   // ---- epilogue.  Lane (pixel fr of tile tp, half fh) holds couts [16 fh, 16 fh + 16) of cout tile tc.
@@ -405,7 +452,13 @@ template <typename T, typename OutT>
 static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   dim3 block(256);
   const int z = phases * a.splitk;
-  if (tile == 128 && a.bp64 == 2) {
+  if (tile == 128 && a.bp64 && a.kg == 3) {
+    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1, 2, 3>), grid, dim3(768), 0, s, a);
+  } else if (tile == 128 && a.bp64 && a.kg == 2) {
+    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
+    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1, 2, 2>), grid, dim3(512), 0, s, a);
+  } else if (tile == 128 && a.bp64 == 2) {
     dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
     hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1, 3>), grid, block, 0, s, a);
   } else if (tile == 128 && a.bp64) {

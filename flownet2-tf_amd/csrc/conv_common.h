@@ -21,6 +21,7 @@ struct ConvArgs {
   int deconv;   // 1: four output phases in blockIdx.z (transposed convolutions), output pixel (2m+a, 2m'+b)
   int ph_pad0, ph_pad1;  // tap origin of phase a = 0 / 1: input row = m - ph_pad + t
   int bp64;     // LDS-DMA kernel: half-width pixel tiles (128x64 / 64x128 / 32x128), see wants_bp64 in conv.hip
+  int kg;       // LDS-DMA kernel, 128 x 64 tiles: K groups per block (1, 2 or 3; conv2.hip), see build_args in conv.hip
   int accum;    // 1: out += result (fp32 outputs; gradient accumulation into shared buffers)
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
   int splitk;  // K splits (blockIdx.z = phase*splitk + split); > 1 -> raw fp32 partials go to `ws`

@@ -40,6 +40,11 @@ def conv2_kernel_args(tile, m, cout_pad, phases):
     if tile < 128:
         return {64: "1, 4, 2, 1", 32: "1, 4, 1, 1"}[tile]
     blocks = -(-m // 64) * (cout_pad // 128) * phases
+    if int(os.environ.get("FN2_KG", "1")):  # K groups (conv.hip: build_args): grids of at most one block per CU
+        if blocks <= int(os.environ.get("FN2_KG3_MAX", "0")):
+            return "2, 2, 2, 1, 2, 3"
+        if blocks <= int(os.environ.get("FN2_KG2_MAX", "95")):
+            return "2, 2, 2, 1, 2, 2"
     if blocks >= int(os.environ.get("FN2_BP64_MIN", "96")):
         # 128 x 64 tiles; the 3-slot ring instantiation (STAGES = 3) for one-round grids without split-K (conv.hip)
         ring = 384 <= blocks <= int(os.environ.get("FN2_RING_MAX", "512"))
