@@ -265,6 +265,11 @@ static bool corr_fast_ok(int C, int esz, int k, int md, int s1, int s2, int pad)
 
 // corr2.hip
 bool corr2_ok(int C, int dtype, int md, int s2, long b_bytes);
+// corr3.hip: the FlowNetC attribute set on 16-bit / split-fp16 features (same-parity row pairs and columns, LDS output tile)
+bool corr3_ok(int C, int in_dtype, int out_dtype, int md, int s2, int H, int out_cs, int out_c0, long b_bytes);
+int launch_corr3(const void* a, int a_cs, int a_c0, const void* b, int b_cs, int b_c0, void* out, int out_cs,
+                 int out_c0, int in_dtype, int out_dtype, int N, int H, int W, int C, int md, int s2, int gr, int gw,
+                 int act, hipStream_t s);
 int launch_corr2(const void* a, int a_cs, int a_c0, const void* b, int b_cs, int b_c0, void* out, int out_cs,
                  int out_c0, int in_dtype, int out_dtype, int N, int H, int W, int C, int md, int s2, int gr, int gw,
                  int act, hipStream_t s);
@@ -300,6 +305,40 @@ int fn2_correlation_f32(const float* a, const float* b, float* out, int n, int h
   return launch_corr<float, float>(g, c, (hipStream_t)stream);
 }
 
+// The op surface on the split-fp16 matrix-core kernel (corr3.hip): fp32 features are rewritten once as split fp16
+// (x = hi + lo, 22 bits; the same 4 bytes per value) into a caller-provided workspace and multiplied with 3 fp16 MFMAs
+// per product instead of fp32 MFMAs at a sixteenth of the rate.  0 bytes = this geometry stays on fn2_correlation_f32.
+static bool corr_ws_path(int n, int h, int w, int c, int k, int md, int s1, int s2, int pad) {
+  return k == 1 && s1 == 1 && pad == md && c % 32 == 0 &&
+         corr3_ok(c, FN2_F16X2, FN2_F32, md, s2, h, 441, 0, (long)n * h * w * c * 4);
+}
+
+int64_t fn2_correlation_workspace_bytes(int n, int h, int w, int c, int k, int md, int s1, int s2, int pad) {
+  if (n < 1 || h < 1 || w < 1 || c < 1) return 0;
+  return corr_ws_path(n, h, w, c, k, md, s1, s2, pad) ? 2 * (int64_t)n * h * w * c * 4 : 0;
+}
+
+int fn2_correlation_f32_ws(const float* a, const float* b, float* out, int n, int h, int w, int c, int k, int md,
+                           int s1, int s2, int pad, void* workspace, int64_t workspace_bytes, void* stream) {
+  FN2_REQUIRE(a && b && out, "correlation: null pointer");
+  FN2_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "input_a must have rank 4");  // correlation_kernel.cc:31
+  const int64_t need = fn2_correlation_workspace_bytes(n, h, w, c, k, md, s1, s2, pad);
+  if (need == 0 || workspace == nullptr || workspace_bytes < need)
+    return fn2_correlation_f32(a, b, out, n, h, w, c, k, md, s1, s2, pad, stream);
+  int oh, ow, gr, gw;
+  int rc = correlation_geometry(h, w, k, md, s1, s2, pad, &oh, &ow, &gr, &gw);
+  if (rc) return rc;
+  const int64_t cnt = (int64_t)n * h * w * c;
+  char* wa = reinterpret_cast<char*>(workspace);
+  char* wb = wa + cnt * 4;
+  rc = fn2_to_f16x2(wa, a, nullptr, cnt, 1.f, stream);
+  if (rc) return rc;
+  rc = fn2_to_f16x2(wb, b, nullptr, cnt, 1.f, stream);
+  if (rc) return rc;
+  return launch_corr3(wa, c, 0, wb, c, 0, out, gw * gw, 0, FN2_F16X2, FN2_F32, n, h, w, c, md, s2, gr, gw, FN2_ACT_NONE,
+                      (hipStream_t)stream);
+}
+
 int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_tensor* out, int md, int s2,
                           int act, void* stream) {
   FN2_REQUIRE(a && b && out && a->data && b->data && out->data, "correlation_fused: null tensor");
@@ -318,6 +357,9 @@ int fn2_correlation_fused(const fn2_tensor* a, const fn2_tensor* b, const fn2_te
                   (b->c0 * esz) % 16 == 0,
               "correlation_fused: feature views must be 16-byte aligned");
   FN2_REQUIRE(out->dtype == a->dtype || out->dtype == FN2_F32, "correlation_fused: bad output dtype");
+  if (corr3_ok(a->c, a->dtype, out->dtype, md, s2, a->h, out->cs, out->c0, (long)b->n * b->h * b->w * b->cs * esz))
+    return launch_corr3(a->data, a->cs, a->c0, b->data, b->cs, b->c0, out->data, out->cs, out->c0, a->dtype,
+                        out->dtype, a->n, a->h, a->w, a->c, md, s2, gr, gw, act, (hipStream_t)stream);
   if (corr2_ok(a->c, a->dtype, md, s2, (long)b->n * b->h * b->w * b->cs * esz))
     return launch_corr2(a->data, a->cs, a->c0, b->data, b->cs, b->c0, out->data, out->cs, out->c0, a->dtype,
                         out->dtype, a->n, a->h, a->w, a->c, md, s2, gr, gw, act, (hipStream_t)stream);

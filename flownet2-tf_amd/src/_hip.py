@@ -53,6 +53,8 @@ PROTOTYPES = {
     "fn2_device_info": (_i, [C.c_char_p, _i, _ip]),
     "fn2_correlation_out_shape": (_i, [_i] * 7 + [_ip] * 3),
     "fn2_correlation_f32": (_i, [_p, _p, _p] + [_i] * 9 + [_p]),
+    "fn2_correlation_workspace_bytes": (C.c_int64, [_i] * 9),
+    "fn2_correlation_f32_ws": (_i, [_p, _p, _p] + [_i] * 9 + [_p, C.c_int64, _p]),
     "fn2_correlation_grad_f32": (_i, [_p] * 5 + [_i] * 9 + [_p]),
     "fn2_flow_warp_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fn2_flow_warp_grad_f32": (_i, [_p] * 5 + [_i] * 4 + [_p]),

@@ -34,8 +34,15 @@ def _forward(a, b, k, md, s1, s2, pad):
     n, h, w, c = a.shape
     oh, ow, oc = _out_shape(h, w, k, md, s1, s2, pad)
     out = torch.empty((n, oh, ow, oc), dtype=torch.float32, device=a.device)
-    _hip.check(_hip.lib().fn2_correlation_f32(_hip.ptr(a), _hip.ptr(b), _hip.ptr(out), n, h, w, c,
-                                              k, md, s1, s2, pad, _hip.stream_ptr()))
+    lib = _hip.lib()
+    need = int(lib.fn2_correlation_workspace_bytes(n, h, w, c, k, md, s1, s2, pad))
+    if need > 0:  # the FlowNetC attribute set: split-fp16 copies of the features + the matrix-core kernel
+        ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+        _hip.check(lib.fn2_correlation_f32_ws(_hip.ptr(a), _hip.ptr(b), _hip.ptr(out), n, h, w, c, k, md, s1, s2, pad,
+                                              _hip.ptr(ws), need, _hip.stream_ptr()))
+        return out
+    _hip.check(lib.fn2_correlation_f32(_hip.ptr(a), _hip.ptr(b), _hip.ptr(out), n, h, w, c,
+                                       k, md, s1, s2, pad, _hip.stream_ptr()))
     return out
 
 

@@ -559,7 +559,7 @@ class Engine:
         self.keep += [va, vb, vo]
         tn = _TNAME[self.dtype_name]
         self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
-                 _hip.ACT_LEAKY, kernel=f"corr2_kernel<{tn}, {tn}, {4 if self.dtype_name in ('bf16', 'f16') else 8}>")  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
+                 _hip.ACT_LEAKY, kernel=self._corr_kernel_name(tn, H // 8))  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
         self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
         # a and b read once, the 441 displacement channels written once, in the reference's fp32 terms
         # (11.71 MB per sample at 48 x 64)
@@ -592,6 +592,14 @@ class Engine:
         c6_1 = self._encoder_tail(scope, tag, L, cats)
         preds = self._refine(scope, tag, L, c6_1, cats, True)
         return self._final_flow(tag, preds, 0.05)  # flownet_sd.py:106-110
+
+    def _corr_kernel_name(self, tn, h):
+        """Device kernel fn2_correlation_fused picks (corr.hip): corr3 (same-parity row pairs) for 16-bit / split-fp16
+        features when the feature height is a multiple of 4, else corr2."""
+        nl = 4 if self.dtype_name in ("bf16", "f16") else 8
+        if self.dtype_name != "f32" and h % 4 == 0 and int(os.environ.get("FN2_CORR3", "1")):
+            return f"corr3_kernel<{tn}, {tn}, {nl}>"
+        return f"corr2_kernel<{tn}, {tn}, {nl}>"
 
     def _pair_input(self, tag, pad):
         """[a | b] with the stem's zero border of `pad` pixels baked in (flownet_s.py:24,39)."""

@@ -96,6 +96,16 @@ int fn2_correlation_out_shape(int h, int w, int kernel_size, int max_displacemen
 int fn2_correlation_f32(const float* a, const float* b, float* out, int n, int h, int w, int c,
                         int kernel_size, int max_displacement, int stride_1, int stride_2, int pad,
                         void* stream);
+/* The same op with a caller-provided scratch buffer (the reference allocates its padded copies through
+ * ctx->allocate_temp, correlation_kernel.cc:61-80): for the FlowNetC attribute set (kernel 1, max_displacement 20,
+ * stride_2 2, pad 20; C % 32 == 0, H % 8 == 0) the features are rewritten as split fp16 (hi + lo, 22 bits) in the
+ * workspace and the cost volume runs on the fp16 matrix cores (3 MFMAs per product); other geometries, a NULL or a too
+ * small workspace fall through to fn2_correlation_f32.  fn2_correlation_workspace_bytes returns 0 for those. */
+int64_t fn2_correlation_workspace_bytes(int n, int h, int w, int c, int kernel_size, int max_displacement, int stride_1,
+                                        int stride_2, int pad);
+int fn2_correlation_f32_ws(const float* a, const float* b, float* out, int n, int h, int w, int c, int kernel_size,
+                           int max_displacement, int stride_1, int stride_2, int pad, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* grad_a, grad_b (same shape as a) from grad_out (correlation_grad_kernel.cu.cc:20-189). */
 int fn2_correlation_grad_f32(const float* grad_out, const float* a, const float* b, float* grad_a,

@@ -62,6 +62,15 @@ def main():
     ms = timed(lambda: _hip.check(lib.fn2_correlation_f32(P_(fa), P_(fb), P_(co), N, h8, w8, 256, 1, 20, 1, 2, 20, st())),
                a.rounds, a.inner)
     rec("correlation_f32", ms, N * h8 * w8 * (2 * 256 + 441) * 4, "read A, B once + write 441 channels")
+    # the same op with a caller-provided workspace: split-fp16 copies of the features + the fp16 matrix-core kernel
+    # (what src.correlation.correlation calls for the FlowNetC attribute set)
+    need = int(lib.fn2_correlation_workspace_bytes(N, h8, w8, 256, 1, 20, 1, 2, 20))
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ms = timed(lambda: _hip.check(lib.fn2_correlation_f32_ws(P_(fa), P_(fb), P_(co), N, h8, w8, 256, 1, 20, 1, 2, 20,
+                                                                 P_(ws), need, st())), a.rounds, a.inner)
+        rec("correlation_f32_ws", ms, N * h8 * w8 * (2 * 256 + 441) * 4,
+            "read A, B once + write 441 channels (+ the two split-fp16 conversion passes, inside the timed call)")
     # the backward ops of SURVEY 8(a) row a12 (used only when a network with these ops is trained)
     gco, gda, gdb = rnd(N, h8, w8, 441), buf(N, h8, w8, 256), buf(N, h8, w8, 256)
     ms = timed(lambda: _hip.check(lib.fn2_correlation_grad_f32(P_(gco), P_(fa), P_(fb), P_(gda), P_(gdb), N, h8, w8, 256,
