@@ -272,6 +272,25 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTensor* __res
   }
 }
 
+// The same with the per-step scalars read from device memory {lr_t, beta1, beta2, eps, grad_scale}: the launch
+// arguments no longer change from step to step, so the whole train step can be replayed as a hipGraph.
+__global__ void __launch_bounds__(256) adam_multi_dev_kernel(const AdamTensor* __restrict__ tab, const long* __restrict__ n,
+                                                             const float* __restrict__ l2, const float* __restrict__ hyper) {
+  const AdamTensor t = tab[blockIdx.y];
+  const long cnt = n[blockIdx.y];
+  const float reg = l2[blockIdx.y];
+  const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gscale = hyper[4];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
+    const float wi = t.w[i];
+    const float gi = t.g[i] * gscale + reg * wi;
+    const float mi = b1 * t.m[i] + (1.f - b1) * gi;
+    const float vi = b2 * t.v[i] + (1.f - b2) * gi * gi;
+    t.m[i] = mi;
+    t.v[i] = vi;
+    t.w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
 // upsample_flowXtoY backward (forward: conv-transpose 2->2, k4 s2 crop 1, upsample_flow_kernel in conv.hip):
 //   dpf[n,y,x,i] (+)= sum_{ky,kx,o} g[n,2y+ky-1,2x+kx-1,o] * w[ky,kx,o,i];  dw[ky,kx,o,i] += sum g * pf
 template <typename T>
@@ -908,6 +927,15 @@ int fn2_adam_step_multi(const void* table, const int64_t* counts, const float* l
   hipLaunchKernelGGL(adam_multi_kernel, dim3(128, n_tensors), dim3(256), 0, (hipStream_t)stream,
                      (const AdamTensor*)table, (const long*)counts, l2, lr_t, beta1, beta2, eps, grad_scale);
   FN2_CHECK_LAUNCH("adam_multi");
+  return FN2_OK;
+}
+
+int fn2_adam_step_multi_dev(const void* table, const int64_t* counts, const float* l2, int n_tensors, const float* hyper,
+                            void* stream) {
+  FN2_REQUIRE(table && counts && l2 && hyper && n_tensors >= 1 && n_tensors <= 65535, "adam_step_multi_dev: bad arguments");
+  hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(128, n_tensors), dim3(256), 0, (hipStream_t)stream,
+                     (const AdamTensor*)table, (const long*)counts, l2, hyper);
+  FN2_CHECK_LAUNCH("adam_multi_dev");
   return FN2_OK;
 }
 

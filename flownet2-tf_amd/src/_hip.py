@@ -82,6 +82,7 @@ PROTOTYPES = {
     "fn2_to_f16x2": (_i, [_p, _p, _p, C.c_int64, _f, _p]),
     "fn2_adam_step": (_i, [_p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _i, _f, _f, _p]),
     "fn2_adam_step_multi": (_i, [_p, _p, _p, _i, _f, _f, _f, _f, _i, _f, _p]),
+    "fn2_adam_step_multi_dev": (_i, [_p, _p, _p, _i, _p, _p]),
     "fn2_upsample_flow_bwd": (_i, [_tp, _p, _p, _p, _p, _i, _p]),
     "fn2_head_bwd_filter": (_i, [_tp, _p, _p, _i, _i, _p]),
     "fn2_head_bwd_data": (_i, [_p, _p, _tp, _i, _i, _p]),

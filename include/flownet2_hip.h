@@ -274,6 +274,11 @@ int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float
  * coefficients (0 where the reference does not regularise). */
 int fn2_adam_step_multi(const void* table, const int64_t* counts, const float* l2, int n_tensors, float lr, float beta1,
                         float beta2, float eps, int step, float grad_scale, void* stream);
+/* fn2_adam_step_multi with the per-step scalars in device memory: hyper = {lr_t, beta1, beta2, eps, grad_scale} with
+ * lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) (tf.train.AdamOptimizer's form, net.py:1290-1295).  The launch
+ * arguments are then the same every step, which lets the train step be captured once and replayed as a hipGraph. */
+int fn2_adam_step_multi_dev(const void* table, const int64_t* counts, const float* l2, int n_tensors, const float* hyper,
+                            void* stream);
 /* upsample_flowXtoY backward: g = gradient view [n,2h,2w,2] of its output slice, pf its fp32 input [n,h,w,2],
  * w [4][4][2][2]; dpf (+)= input gradient, dw += filter gradient. */
 int fn2_upsample_flow_bwd(const fn2_tensor* g, const float* pf, const float* w, float* dpf, float* dw,

@@ -139,6 +139,34 @@ def test_adam_steps_match_oracle(dtype):
             assert bad.mean() < 1e-2 and np.median(diff) < 1e-3 * np.abs(move_want).max(), (name, bad.mean())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_captured_train_step_equals_eager(dtype, monkeypatch):
+    """train_step replays the step as a hipGraph (Adam's per-step scalars in device memory): three steps from the same
+    weights on the same batches end at the same weights and Adam moments as the eager launch sequence (the filter
+    gradients are summed with fp32 atomics, so equality is to rounding, not bit for bit), and the loss is the same."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetS", 6)
+    batches = [data(2, 128, 128, 20 + i) for i in range(3)]
+    monkeypatch.setenv("FN2_TRAIN_GRAPH", "0")
+    eager = FlowNetSTrainer(wts, 2, 128, 128, dtype=dtype)
+    le = [float(eager.train_step(*b).item()) for b in batches]
+    monkeypatch.setenv("FN2_TRAIN_GRAPH", "1")
+    graph = FlowNetSTrainer(wts, 2, 128, 128, dtype=dtype)
+    lg = [float(graph.train_step(*b).item()) for b in batches]
+    assert graph._step_graphs is not None and eager.step_count == graph.step_count == 3
+    np.testing.assert_allclose(lg, le, rtol=1e-5)
+    for pe, pg in zip(eager.params, graph.params):
+        we, wg = pe["w"].cpu().numpy(), pg["w"].cpu().numpy()
+        # three steps of lr 1e-4 move a weight by <= 3e-4; the two paths differ by gradient rounding only (an element
+        # whose gradient is within that rounding of zero may step the other way: bound the share of such elements)
+        diff = np.abs(we - wg)
+        assert diff.max() <= 6.1e-4 and (diff > 3e-5).mean() < 1e-2, (pe["name"], diff.max())
+        ve, vg = pe["v"].cpu().numpy(), pg["v"].cpu().numpy()
+        assert np.abs(vg - ve).max() <= 2e-3 * max(np.abs(ve).max(), 1e-30), pe["name"]
+
+
 def _dp_worker(rank, world, port, out_path):
     """One data-parallel rank on the shared test GPU (gloo rendezvous: RCCL needs one device per rank)."""
     import torch.distributed as dist
