@@ -83,7 +83,10 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
 // epilogue -- split-K inside the workgroup.  Used on the 6x8 / 12x16 levels (grids under 96 blocks of 128 x 64), where
 // it halves the number of partial-sum slabs the split-K finalize pass has to read (policy and measurements: conv.hip,
 // build_args).
-template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2, int KG = 1>
+// M16 = the 16x16x32 matrix instruction instead of 32x32x16 (split-fp16 operands only; A/B experiment of the guide's
+// "the chip can hold a higher clock on one MFMA shape than on the other"): same LDS image, same fragment reads per
+// FLOP; a lane then holds runs of 4 consecutive output channels instead of 16.
+template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2, int KG = 1, bool M16 = false>
 __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
@@ -232,6 +235,14 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     for (int tp = 0; tp < TPN; ++tp)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[tc][tp][q] = 0.f;
+  // M16: 16 x 16 sub-tiles (sc, sp) of the wave's (TCN*32) x (TPN*32) tile
+  f32x4 acc16[M16 ? TCN * 2 : 1][M16 ? TPN * 2 : 1];
+  if constexpr (M16) {
+#pragma unroll
+    for (int a = 0; a < TCN * 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TPN * 2; ++b) acc16[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // one stage of MFMAs on the LDS object `lds`
   auto compute = [&](const uint4* lds) {
@@ -240,7 +251,32 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 #endif
     const uint4* A = &lds[(wc * TCN * 32 + fr) * 8];
     const uint4* B = &lds[(BC + wp * TPN * 32 + fr) * 8];
-    if constexpr (is_x2<T>::value) {
+    if constexpr (is_x2<T>::value && M16) {
+      // 16x16x32: lane (row l & 15, channel group g = l >> 4) reads the hi chunk 2g and the lo chunk 2g + 1 of its
+      // row; one instruction covers the stage's 32 channels
+      const int r16 = lane & 15, g16 = lane >> 4;
+      uint4 ah[TCN * 2], al[TCN * 2], bh[TPN * 2], bl[TPN * 2];
+#pragma unroll
+      for (int t = 0; t < TCN * 2; ++t) {
+        const int row = wc * TCN * 32 + t * 16 + r16, sw = (row >> 1) & 7;
+        ah[t] = lds[row * 8 + ((2 * g16) ^ sw)];
+        al[t] = lds[row * 8 + ((2 * g16 + 1) ^ sw)];
+      }
+#pragma unroll
+      for (int t = 0; t < TPN * 2; ++t) {
+        const int row = BC + wp * TPN * 32 + t * 16 + r16, sw = (row >> 1) & 7;
+        bh[t] = lds[row * 8 + ((2 * g16) ^ sw)];
+        bl[t] = lds[row * 8 + ((2 * g16 + 1) ^ sw)];
+      }
+#pragma unroll
+      for (int a = 0; a < TCN * 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TPN * 2; ++b) {
+          acc16[a][b] = mfma_16x16x32<f16_t>(al[a], bh[b], acc16[a][b]);
+          acc16[a][b] = mfma_16x16x32<f16_t>(ah[a], bl[b], acc16[a][b]);
+          acc16[a][b] = mfma_16x16x32<f16_t>(ah[a], bh[b], acc16[a][b]);
+        }
+    } else if constexpr (is_x2<T>::value) {
       // split fp16: the 128-byte row is [hi g0 | lo g0 | hi g1 | lo g1 | hi g2 | lo g2 | hi g3 | lo g3]
       // (4 groups of 8 channels).  One 32x32x16 product covers groups (2q, 2q+1): lane half h owns
       // group 2q+h, i.e. chunks 4q+2h (hi) and 4q+2h+1 (lo);  x*w = hi*hi + hi*lo + lo*hi.
@@ -357,33 +393,84 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   if constexpr (KG > 1) {
     // sum the K groups through LDS (every wave is past the loop's last barrier: the stage buffers are free), group 1
     // first, then group 2: a fixed order, so the result does not depend on timing
-    constexpr int NA4 = TCN * TPN * 4;
+    constexpr int NA4 = TCN * TPN * 4;  // float4 of accumulators per lane (the same 16 x TCN x TPN floats in either MFMA shape)
     static_assert((KG - 1) * 4 * NA4 * 64 <= KG * ROWS * 8, "reduction scratch must fit the stage buffers");
     float4* red = reinterpret_cast<float4*>(lds0_all);
+    auto acc4 = [&](int idx) -> float4 {  // idx-th float4 of this lane's accumulators
+      if constexpr (M16) {
+        const f32x4 v = acc16[idx / (TPN * 2)][idx % (TPN * 2)];
+        return make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        const int t = idx >> 2, q = idx & 3;
+        return make_float4(acc[t / TPN][t % TPN][4 * q], acc[t / TPN][t % TPN][4 * q + 1], acc[t / TPN][t % TPN][4 * q + 2],
+                           acc[t / TPN][t % TPN][4 * q + 3]);
+      }
+    };
     if (grp > 0) {
 #pragma unroll
-      for (int tc = 0; tc < TCN; ++tc)
-#pragma unroll
-        for (int tp = 0; tp < TPN; ++tp)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            red[(((grp - 1) * 4 + wave) * NA4 + (tc * TPN + tp) * 4 + q) * 64 + lane] =
-                make_float4(acc[tc][tp][4 * q], acc[tc][tp][4 * q + 1], acc[tc][tp][4 * q + 2], acc[tc][tp][4 * q + 3]);
+      for (int idx = 0; idx < NA4; ++idx) red[(((grp - 1) * 4 + wave) * NA4 + idx) * 64 + lane] = acc4(idx);
     }
     __syncthreads();
     if (grp > 0) return;
 #pragma unroll
     for (int g = 0; g < KG - 1; ++g)
 #pragma unroll
-      for (int tc = 0; tc < TCN; ++tc)
+      for (int idx = 0; idx < NA4; ++idx) {
+        const float4 v = red[((g * 4 + wave) * NA4 + idx) * 64 + lane];
+        if constexpr (M16) {
+          f32x4& d = acc16[idx / (TPN * 2)][idx % (TPN * 2)];
+          d[0] += v.x; d[1] += v.y; d[2] += v.z; d[3] += v.w;
+        } else {
+          const int t = idx >> 2, q = idx & 3;
+          acc[t / TPN][t % TPN][4 * q] += v.x; acc[t / TPN][t % TPN][4 * q + 1] += v.y;
+          acc[t / TPN][t % TPN][4 * q + 2] += v.z; acc[t / TPN][t % TPN][4 * q + 3] += v.w;
+        }
+      }
+  }
+
+  if constexpr (M16) {
+    // D of a 16 x 16 sub-tile: column (pixel) = lane & 15, rows (packed weight rows) 4 (lane >> 4) + j.  With the row
+    // permutation of the 32 x 32 layout (packed row (r & 3) + 8 (r >> 2) + 4 h <-> cout 16 h + r) the four rows of a
+    // lane are the consecutive couts 16 (g & 1) + 8 s + 4 (g >> 1) + j of their 32-cout group (s = sub-tile parity).
+    OutT* out16 = reinterpret_cast<OutT*>(p.out);
+    const int r16 = lane & 15, g16 = lane >> 4;
+    float* slab = p.splitk > 1 ? p.ws + (size_t)split * p.N * p.out_H * p.out_W * p.ws_cs : nullptr;
 #pragma unroll
-        for (int tp = 0; tp < TPN; ++tp)
+    for (int b = 0; b < TPN * 2; ++b) {
+      const int m = m0 + wp * TPN * 32 + b * 16 + r16;
+      if (m >= p.M) continue;
+      const int n = m / (p.OH * p.OW);
+      const int rem = m - n * (p.OH * p.OW);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const size_t opix = ((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off);
+      OutT* po = out16 + opix * p.out_cs + p.out_c0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 v = red[((g * 4 + wave) * NA4 + (tc * TPN + tp) * 4 + q) * 64 + lane];
-            acc[tc][tp][4 * q] += v.x; acc[tc][tp][4 * q + 1] += v.y;
-            acc[tc][tp][4 * q + 2] += v.z; acc[tc][tp][4 * q + 3] += v.w;
+      for (int a = 0; a < TCN * 2; ++a) {
+        const int co = c0 + wc * TCN * 32 + (a >> 1) * 32 + 16 * (g16 & 1) + 8 * (a & 1) + 4 * (g16 >> 1);
+        if (slab != nullptr) {  // raw fp32 partial sums; bias / activation in the finalize pass
+          if (co < p.ws_cs)
+            *reinterpret_cast<float4*>(slab + opix * p.ws_cs + co) =
+                make_float4(acc16[a][b][0], acc16[a][b][1], acc16[a][b][2], acc16[a][b][3]);
+          continue;
+        }
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = acc16[a][b][j] * p.out_scale + ((p.bias != nullptr && co + j < p.Cout) ? p.bias[co + j] : 0.f);
+          if constexpr (sizeof(OutT) == 4) {
+            if (p.accum && co + j < p.Cout) x += load_elem<OutT>(po + co + j);
           }
+          if (p.act == FN2_ACT_LEAKY) x = leaky(x);
+          v[j] = x;
+        }
+        if (p.vec_ok && co + 3 < p.Cout) store_vec<OutT, 4>(po + co, v);
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.Cout) store_elem<OutT>(po + co + j, v[j]);
+      }
+    }
+    return;
   }
 
   // ---- epilogue.  Lane (pixel fr of tile tp, half fh) holds couts [16 fh, 16 fh + 16) of cout tile tc.
@@ -450,36 +537,36 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 
 template <typename T, typename OutT>
 static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
-  dim3 block(256);
   const int z = phases * a.splitk;
-  if (tile == 128 && a.bp64 && a.kg == 3) {
-    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1, 2, 3>), grid, dim3(768), 0, s, a);
-  } else if (tile == 128 && a.bp64 && a.kg == 2) {
-    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1, 2, 2>), grid, dim3(512), 0, s, a);
-  } else if (tile == 128 && a.bp64 == 2) {
-    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1, 3>), grid, block, 0, s, a);
-  } else if (tile == 128 && a.bp64) {
-    dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 2, 1>), grid, block, 0, s, a);
-  } else if (tile == 128) {
-    dim3 grid(cdiv(a.M, 128), a.cout_pad / 128, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2>), grid, block, 0, s, a);
-  } else if (tile == 64 && a.bp64) {
-    dim3 grid(cdiv(a.M, 128), a.cout_pad / 64, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4, 2, 1>), grid, block, 0, s, a);
-  } else if (tile == 64) {
-    dim3 grid(cdiv(a.M, 256), a.cout_pad / 64, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4>), grid, block, 0, s, a);
-  } else if (a.bp64) {
-    dim3 grid(cdiv(a.M, 128), a.cout_pad / 32, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4, 1, 1>), grid, block, 0, s, a);
-  } else {
-    dim3 grid(cdiv(a.M, 256), a.cout_pad / 32, z);
-    hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 1, 4, 1>), grid, block, 0, s, a);
-  }
+  // M16 = the 16x16x32 instruction for split-fp16 operands (same LDS traffic per FLOP).  On single layers that are
+  // matrix-bound it is +5..7 % (conv2 b8 312 -> 327, conv3_1 b8 308 -> 324, conv3_1 at batch 64 354 -> 380 TFLOP/s;
+  // tools/ab_conv.py variants 0,1024) -- the guide's "the chip holds a higher clock on this shape".  End to end at the
+  // BASELINE batch sizes it does not pay: FlowNet2 b4 4.34 -> 4.38 ms, FlowNetC b8 1.570 -> 1.562 ms with it on the
+  // plain 128 x 64 layers of >= 768 blocks; on the ring +4 % time, on the 64- / 32-cout tiles +8 % / +5.5 % (runs of 4
+  // output channels per lane double the store instructions of layers bound by stores and L2 -> LDS traffic).  So it
+  // is OFF by default: FN2_M16_MIN = smallest plain 128 x 64 grid that takes it (e.g. 768 for large-batch serving),
+  // FN2_CONV_DBG bit 1024 = on every split-fp16 tile (A/B).
+  const long blocks64 = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * z;
+  const char* e_m16 = getenv("FN2_M16_MIN");
+  const bool m16 = is_x2<T>::value && !(a.dbg & 512) &&
+                   ((a.dbg & 1024) || (e_m16 && tile == 128 && a.bp64 == 1 && a.kg == 1 && a.splitk == 1 &&
+                                       blocks64 >= atoi(e_m16)));
+#define FN2_LAUNCH2(GX, GY, THREADS, ...)                                                              \
+  do {                                                                                                 \
+    dim3 grid(GX, GY, z);                                                                              \
+    if (m16) hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, __VA_ARGS__, is_x2<T>::value>), grid, dim3(THREADS), 0, s, a); \
+    else hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, __VA_ARGS__, false>), grid, dim3(THREADS), 0, s, a);            \
+  } while (0)
+  if (tile == 128 && a.bp64 && a.kg == 3) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 768, 2, 2, 2, 1, 2, 3);
+  else if (tile == 128 && a.bp64 && a.kg == 2) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 512, 2, 2, 2, 1, 2, 2);
+  else if (tile == 128 && a.bp64 == 2) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 256, 2, 2, 2, 1, 3, 1);
+  else if (tile == 128 && a.bp64) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 256, 2, 2, 2, 1, 2, 1);
+  else if (tile == 128) FN2_LAUNCH2(cdiv(a.M, 128), a.cout_pad / 128, 256, 2, 2, 2, 2, 2, 1);
+  else if (tile == 64 && a.bp64) FN2_LAUNCH2(cdiv(a.M, 128), a.cout_pad / 64, 256, 1, 4, 2, 1, 2, 1);
+  else if (tile == 64) FN2_LAUNCH2(cdiv(a.M, 256), a.cout_pad / 64, 256, 1, 4, 2, 2, 2, 1);
+  else if (a.bp64) FN2_LAUNCH2(cdiv(a.M, 128), a.cout_pad / 32, 256, 1, 4, 1, 1, 2, 1);
+  else FN2_LAUNCH2(cdiv(a.M, 256), a.cout_pad / 32, 256, 1, 4, 1, 2, 2, 1);
+#undef FN2_LAUNCH2
   FN2_CHECK_LAUNCH("conv_igemm2");
   return FN2_OK;
 }

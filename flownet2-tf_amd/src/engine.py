@@ -33,23 +33,29 @@ _CODE = {"f32": _hip.FN2_F32, "bf16": _hip.FN2_BF16, "f16": _hip.FN2_F16, "f16x2
 _TILE_ARGS = {128: "2, 2, 2, 2", 64: "1, 4, 2, 2", 32: "1, 4, 1, 2"}  # conv_igemm2_kernel<.., WC, WP, TCN, TPN> per cout tile
 
 
-def conv2_kernel_args(tile, m, cout_pad, phases):
-    """Template arguments of the conv_igemm2_kernel instantiation the library picks (conv.hip: wants_bp64)."""
-    if int(os.environ.get("FN2_CONV_DBG", "0")) & 32:
-        return _TILE_ARGS[tile]
+def conv2_kernel_args(tile, m, cout_pad, phases, x2=True):
+    """Template arguments <WC, WP, TCN, TPN, STAGES, KG, M16> of the conv_igemm2_kernel instantiation the library picks
+    (conv.hip: build_args / wants_bp64; conv2.hip: launch2), as rocprofv3 prints them."""
+    dbg = int(os.environ.get("FN2_CONV_DBG", "0"))
+    blocks64 = -(-m // 64) * (cout_pad // 128) * phases if tile == 128 else 0
+    # M16 (16x16x32 instruction): plain 128 x 64 tiles of large split-fp16 layers without split-K (conv2.hip: launch2)
+    big = "FN2_M16_MIN" in os.environ and blocks64 >= max(int(os.environ["FN2_M16_MIN"]), 513)  # off by default
+    m16 = "true" if (x2 and not dbg & 512 and (dbg & 1024 or big)) else "false"
+    full = dbg & 32
     if tile < 128:
-        return {64: "1, 4, 2, 1", 32: "1, 4, 1, 1"}[tile]
+        base = {64: "1, 4, 2, 2, 2, 1", 32: "1, 4, 1, 2, 2, 1"}[tile] if full else {64: "1, 4, 2, 1, 2, 1", 32: "1, 4, 1, 1, 2, 1"}[tile]
+        return f"{base}, {m16}"
     blocks = -(-m // 64) * (cout_pad // 128) * phases
-    if int(os.environ.get("FN2_KG", "1")):  # K groups (conv.hip: build_args): grids of at most one block per CU
+    if not full and int(os.environ.get("FN2_KG", "1")):  # K groups (conv.hip: build_args): the 6x8 / 12x16 levels
         if blocks <= int(os.environ.get("FN2_KG3_MAX", "0")):
-            return "2, 2, 2, 1, 2, 3"
+            return f"2, 2, 2, 1, 2, 3, {m16}"
         if blocks <= int(os.environ.get("FN2_KG2_MAX", "95")):
-            return "2, 2, 2, 1, 2, 2"
-    if blocks >= int(os.environ.get("FN2_BP64_MIN", "96")):
+            return f"2, 2, 2, 1, 2, 2, {m16}"
+    if not full and blocks >= int(os.environ.get("FN2_BP64_MIN", "96")):
         # 128 x 64 tiles; the 3-slot ring instantiation (STAGES = 3) for one-round grids without split-K (conv.hip)
         ring = 384 <= blocks <= int(os.environ.get("FN2_RING_MAX", "512"))
-        return "2, 2, 2, 1, 3" if ring else "2, 2, 2, 1, 2"
-    return _TILE_ARGS[tile]
+        return f"2, 2, 2, 1, 3, 1, {m16}" if ring else f"2, 2, 2, 1, 2, 1, {m16}"
+    return f"2, 2, 2, 2, 2, 1, {m16}"
 
 
 _TNAME = {"f32": "float", "bf16": "__bf16", "f16": "_Float16", "f16x2": "fn2::x2_t"}
@@ -299,7 +305,7 @@ class Engine:
         elif layout == 1:
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
             m_px = dbuf.shape[0] * dbuf.shape[1] * dbuf.shape[2] // (4 if kind != "conv" else 1)
-            kern = f"conv_igemm2_kernel<{tn}, {on}, {conv2_kernel_args(tile, m_px, cout_pad, 4 if kind != 'conv' else 1)}>"
+            kern = f"conv_igemm2_kernel<{tn}, {on}, {conv2_kernel_args(tile, m_px, cout_pad, 4 if kind != 'conv' else 1, tn == 'fn2::x2_t')}>"
         else:
             shape = {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4", 16: "1, 1, 4"}[tile]
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
@@ -353,7 +359,7 @@ class Engine:
         self.desc_branch.append(self._branch)
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
-                 kernel=f"conv_igemm2_kernel<{tn}, float, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1)}>")
+                 kernel=f"conv_igemm2_kernel<{tn}, float, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1, tn == 'fn2::x2_t')}>")
         self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(head_t), 32,
                  _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd)
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
@@ -411,7 +417,7 @@ class Engine:
                                 kstep=plan.kstep_elems, cs=cs))
         tn = _TNAME[self.dtype_name]
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
-                 kernel=f"conv_igemm2_kernel<{tn}, {tn}, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1)}>")
+                 kernel=f"conv_igemm2_kernel<{tn}, {tn}, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1, tn == 'fn2::x2_t')}>")
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * k_alg * k_alg * cin_alg * cout))
 

@@ -254,7 +254,7 @@ class FlowNetSTrainer:
             gxs = gx_buf.shape
             m_px = gxs[0] * gxs[1] * gxs[2] // (4 if kind == 3 else 1)
             d.kernel_name = "conv_igemm2_kernel<%s, %s, %s>" % (tn, tn, conv2_kernel_args(plan.cout_tile, m_px, cout_pad,
-                                                                                               4 if kind == 3 else 1))
+                                                                                               4 if kind == 3 else 1, self.x2))
         else:
             d.kernel_name = "conv_igemm_kernel<float, float, %s>" % {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4",
                                                                       16: "1, 1, 4"}[plan.cout_tile]
