@@ -4,7 +4,7 @@
 # Writes rocprofv3 kernel statistics, the bench JSON lines and the PMC traffic summaries under gpurun_out/profiles_<tag>/
 # (copy what should be judged into profiles/).  Counters are collected in their own passes (no trace domains mixed in).
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 root=$(pwd)
 out=$root/gpurun_out/profiles_$tag
 mkdir -p $out
@@ -20,12 +20,12 @@ stats() {  # name, bench args...
   echo "stats $name done"
 }
 
-stats flownetc_b8_f16x2 --steps 30 --warmup 5
-stats flownetc_b8_bf16 --steps 30 --warmup 5 --dtype bf16
-stats flownetc_b8_f32 --steps 30 --warmup 5 --dtype f32
-stats flownet2_b4_f16x2 --model FlowNet2 --batch 4 --steps 20 --warmup 3
+# the driver's own command line (FlowNet2 b4, BASELINE config 3) -- without the FlowNetC extra, so that the per-kernel
+# averages of the summary are those of ONE workload
+stats flownet2_b4_f16x2 --no-extra
+stats flownetc_b8_f16x2 --model FlowNetC --batch 8
+stats flownetc_b8_bf16 --model FlowNetC --batch 8 --dtype bf16
 stats flownets_train_b8_f16x2 --mode train --steps 10 --warmup 3
-stats flownets_train_b8_f32 --mode train --train-dtype f32 --steps 10 --warmup 3
 
 pmc() {  # name, counter, bench args...
   local name=$1 counter=$2; shift 2
@@ -33,7 +33,7 @@ pmc() {  # name, counter, bench args...
   rocprofv3 --kernel-trace --pmc $counter -d $out/pmc_${name}_$counter --output-format csv -- python $root/bench.py "$@" \
       --no-cpu-baseline --no-graph --steps 3 --warmup 1 > /dev/null 2> $out/pmc_${name}_$counter.err
 }
-for cfg in "FlowNetC_b8_f16x2 --dtype f16x2" "FlowNetC_b8_f32 --dtype f32" "FlowNet2_b4_f16x2 --model FlowNet2 --batch 4 --dtype f16x2"; do
+for cfg in "FlowNet2_b4_f16x2 --model FlowNet2 --batch 4 --dtype f16x2 --no-extra --regions 1" "FlowNetC_b8_f16x2 --model FlowNetC --batch 8 --dtype f16x2 --regions 1"; do
   set -- $cfg
   name=$1; shift
   pmc $name FETCH_SIZE "$@"
@@ -46,11 +46,10 @@ done
 
 python $root/tools/bench_ops.py > $out/${tag}_ops_bandwidth_b8.json 2> /dev/null
 python $root/tools/bench_ops.py --batch 64 > $out/${tag}_ops_bandwidth_b64.json 2> /dev/null
-# the plain (un-profiled) headline run, CPU baseline included
-python $root/bench.py --steps 30 --warmup 5 > $out/${tag}_flownetc_b8_f16x2_bench.json 2> /dev/null
-python $root/bench.py --model FlowNet2 --batch 4 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_flownet2_b4_f16x2_bench.json 2> /dev/null
-python $root/bench.py --model FlowNet2 --batch 4 --height 448 --width 1024 --steps 10 --warmup 3 --no-cpu-baseline \
+# the plain (un-profiled) headline run: the driver's command line, CPU baseline and the FlowNetC extra included
+python $root/bench.py > $out/${tag}_default_flownet2_b4_f16x2_bench.json 2> /dev/null
+python $root/bench.py --height 448 --width 1024 --steps 10 --warmup 3 --no-cpu-baseline \
     > $out/${tag}_flownet2_b4_1024x448_f16x2_bench.json 2> /dev/null
+python $root/bench.py --model FlowNetS --batch 8 --no-extra --no-cpu-baseline > $out/${tag}_flownets_b8_f16x2_bench.json 2> /dev/null
 python $root/bench.py --mode train --steps 10 --warmup 3 > $out/${tag}_flownets_train_b8_f16x2_bench.json 2> /dev/null
-python $root/bench.py --mode train --train-dtype f32 --steps 10 --warmup 3 > $out/${tag}_flownets_train_b8_f32_bench.json 2> /dev/null
 ls -la $out
