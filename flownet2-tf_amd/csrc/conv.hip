@@ -880,6 +880,16 @@ int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d) {
   return s > 1 ? split_bytes(a, s) : 0;
 }
 
+int fn2_conv2d_kernel_name(const fn2_conv_desc* d, char* name, int cap) {
+  FN2_REQUIRE(name && cap > 0, "conv2d_kernel_name: no buffer");
+  name[0] = 0;
+  if (!d || d->wgt_layout != 1 || is_flow_head(d)) return FN2_OK;  // only the LDS-DMA launchers report their choice
+  conv_name_sink() = ConvNameSink{name, cap};
+  const int rc = fn2_conv2d(d, nullptr);
+  conv_name_sink() = ConvNameSink{nullptr, 0};
+  return rc;
+}
+
 int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   ConvArgs a;
   int tile, phases;
@@ -922,7 +932,7 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   else if (d->in.dtype == FN2_BF16) rc = launch_conv<bf16_t, float>(a, tile, phases, s);
   else if (d->out.dtype == FN2_F16) rc = launch_conv<f16_t, f16_t>(a, tile, phases, s);
   else rc = launch_conv<f16_t, float>(a, tile, phases, s);
-  if (rc || a.splitk == 1) return rc;
+  if (rc || a.splitk == 1 || conv_name_sink().buf) return rc;
   const long npix = (long)a.N * a.out_H * a.out_W;
   const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
   if (d->out.dtype == FN2_F32)

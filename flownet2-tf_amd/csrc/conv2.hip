@@ -535,6 +535,231 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Halo variant for stride-1 layers (3x3 convolutions and the 2x2 phase convolutions of the transposed convs) on
+// split-fp16 operands.  In the kernel above every filter tap fetches its own copy of the tile's pixel rows, although
+// the taps kx = 0..KW-1 of one kernel row read the SAME input pixels shifted by one: a tile of BP consecutive pixels
+// of an image row needs BP + KW - 1 input pixels per (channel block, ky), not KW * BP.  Here the pixel operand is
+// fetched once per (channel block, ky) WITH its halo -- LDS row e <-> input pixel ix0 + e, so a row is valid or zero
+// by the pixel it is, whatever tap reads it -- and tap kx reads the fragment rows r + kx; the weights still move per
+// tap.  L2 -> LDS bytes per (channel block, ky): (KW*BC + BP + KW - 1) rows instead of KW * (BC + BP): -22 % for the
+// 128 x 64 tile, -44 % for 64 x 128, -53 % for 32 x 128 (KW = 3) -- the layers with few output channels (the
+// full-resolution fusion layers, deconv2, interconvN) are bound by exactly that stream.
+// Requires: stride 1, no split-K, tiles that do not straddle image rows (OW % BP == 0).
+template <typename OutT, int WC, int WP, int TCN, int TPN, int KW>
+__global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = x2_t;
+  constexpr int ESZ = 4;
+  constexpr int BC = WC * TCN * 32, BP = WP * TPN * 32;
+  static_assert(WC * WP == 4, "4 waves per block");
+  constexpr int NWI = BC / 32;                // weight pieces (8 rows each) per wave per tap stage
+  constexpr int BROWS = BP + 8;               // BP + KW - 1 pixel rows, whole pieces
+  constexpr int NBP = BROWS / 8;              // pixel pieces per (channel block, ky)
+  constexpr int NBW = (NBP + 3) / 4;          // ... per wave
+  __shared__ uint4 ldsA[2][BC * 8];
+  __shared__ uint4 ldsB[2][BROWS * 8];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+
+  int pad_y = p.pad, pad_x = p.pad, oy_off = 0, ox_off = 0, osc = 1;
+  const T* wgt = reinterpret_cast<const T*>(p.wgt);
+  const int phase = blockIdx.z;
+  const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
+  if (p.deconv) {
+    const int a = phase >> 1, b = phase & 1;
+    pad_y = a ? p.ph_pad1 : p.ph_pad0; pad_x = b ? p.ph_pad1 : p.ph_pad0; oy_off = a; ox_off = b; osc = 2;
+    wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
+  }
+  int bx = blockIdx.x, by = blockIdx.y;
+  {  // XCD-aware tile order (see conv_igemm2_kernel)
+    const int NT = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = L & 7, chunk = NT >> 3, rem = NT & 7;
+    const int Lp = xcd * chunk + min(xcd, rem) + (L >> 3);
+    bx = Lp / (int)gridDim.y;
+    by = Lp - bx * (int)gridDim.y;
+  }
+  const int m0 = bx * BP, c0 = by * BC;
+  // the tile lies inside one image row: (n, oy) are block-uniform
+  const int tn = m0 / (p.OH * p.OW);
+  const int trem = m0 - tn * (p.OH * p.OW);
+  const int toy = trem / p.OW, tox = trem - toy * p.OW;
+  const int iy_base = toy - pad_y, ix_base = tox - pad_x;
+
+  const v4i_t rsrc_w = make_rsrc(wgt, (int)(p.cout_pad * wrow_bytes));
+  const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
+  const int lrow = lane >> 3, lphys = lane & 7;
+  unsigned woff[NWI];
+#pragma unroll
+  for (int j = 0; j < NWI; ++j) {
+    const int row = wave * (BC / 4) + j * 8 + lrow;
+    woff[j] = (unsigned)(c0 + row) * wrow_bytes + (unsigned)((lphys ^ ((row >> 1) & 7)) * 16);
+  }
+  // pixel rows with halo: LDS row e <-> input pixel (tn, iy_base + ky, ix_base + e); x validity is the lane's own
+  int boff[NBW];
+  bool bok[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int q = wave + 4 * j;
+    const int e = q * 8 + lrow;
+    const int ix = ix_base + e;
+    bok[j] = q < NBP && e < BP + KW - 1 && ix >= 0 && ix < p.W;
+    boff[j] = (((tn * p.H + iy_base) * p.W + ix) * p.in_cs + p.in_c0) * ESZ + (lphys ^ ((e >> 1) & 7)) * 16;
+  }
+  const int spt = p.cin_chunks >> 3;       // 128-byte channel blocks per tap
+  const int nsup = spt * p.KH;             // (channel block, ky) super-stages; K order: channel block, ky, kx
+  auto issue_B = [&](int sup, uint4* lds) {
+    const int sc = sup / p.KH, ky = sup - sc * p.KH;
+    const bool yok = (unsigned)(iy_base + ky) < (unsigned)p.H;
+    const int toff = (ky * p.W * p.in_cs) * ESZ + sc * 128;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int q = wave + 4 * j;
+      if (q < NBP) dma16(rsrc_x, &lds[q * 64], (bok[j] && yok) ? (unsigned)(boff[j] + toff) : kOobOffset, 0);
+    }
+  };
+  auto issue_A = [&](int sup, int kx, uint4* lds) {
+    const int sc = sup / p.KH, ky = sup - sc * p.KH;
+    const int soff = ((ky * KW + kx) * spt + sc) * 128;
+#pragma unroll
+    for (int j = 0; j < NWI; ++j) dma16(rsrc_w, &lds[(wave * (BC / 4) + j * 8) * 8], woff[j], soff);
+  };
+
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  f32x16 acc[TCN][TPN];
+#pragma unroll
+  for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TPN; ++tp)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[tc][tp][q] = 0.f;
+
+  auto compute = [&](const uint4* la, const uint4* lb, int kx) {
+#if FN2_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    const uint4* A = &la[(wc * TCN * 32 + fr) * 8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
+      uint4 ah[TCN], al[TCN], bh[TPN], bl[TPN];
+#pragma unroll
+      for (int t = 0; t < TCN; ++t) { ah[t] = A[t * 32 * 8 + chh]; al[t] = A[t * 32 * 8 + chl]; }
+#pragma unroll
+      for (int t = 0; t < TPN; ++t) {
+        const int rb = wp * TPN * 32 + t * 32 + fr + kx, sw = (rb >> 1) & 7;  // tap kx = the same pixels one row on
+        bh[t] = lb[rb * 8 + ((4 * q + 2 * fh) ^ sw)];
+        bl[t] = lb[rb * 8 + ((4 * q + 2 * fh + 1) ^ sw)];
+      }
+#pragma unroll
+      for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TPN; ++tp) {
+          acc[tc][tp] = mfma_32x32x16<f16_t>(al[tc], bh[tp], acc[tc][tp]);
+          acc[tc][tp] = mfma_32x32x16<f16_t>(ah[tc], bl[tp], acc[tc][tp]);
+          acc[tc][tp] = mfma_32x32x16<f16_t>(ah[tc], bh[tp], acc[tc][tp]);
+        }
+    }
+#if FN2_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
+  issue_B(0, ldsB[0]);
+  issue_A(0, 0, ldsA[0]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int abuf = 0;
+  for (int sup = 0; sup < nsup; ++sup) {
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {
+      // the next tap's weights, and with the first tap of a super-stage the NEXT super-stage's pixel rows (two more
+      // tap stages pass before they are read), in flight under this stage's MFMAs
+      if (kx + 1 < KW) issue_A(sup, kx + 1, ldsA[abuf ^ 1]);
+      else if (sup + 1 < nsup) issue_A(sup + 1, 0, ldsA[abuf ^ 1]);
+      if (kx == 0 && sup + 1 < nsup) issue_B(sup + 1, ldsB[(sup + 1) & 1]);
+      compute(ldsA[abuf], ldsB[sup & 1], kx);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      abuf ^= 1;
+    }
+  }
+
+  // ---- epilogue (as conv_igemm2_kernel): lane (pixel fr of tile tp, half fh) holds couts [16 fh, 16 fh + 16) of tile tc
+  OutT* out = reinterpret_cast<OutT*>(p.out);
+  const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
+#pragma unroll
+  for (int tc = 0; tc < TCN; ++tc) {
+    const int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
+    float bias[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bias[q] = (p.bias != nullptr && cout_base + q < p.Cout) ? p.bias[cout_base + q] : 0.f;
+#pragma unroll
+    for (int tp = 0; tp < TPN; ++tp) {
+      const int ox = tox + wp * TPN * 32 + tp * 32 + fr;
+      OutT* po = out + (((size_t)tn * p.out_H + (toy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.out_cs +
+                 p.out_c0 + cout_base;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float x = acc[tc][tp][q] * p.out_scale + bias[q];
+        if constexpr (sizeof(OutT) == 4) {
+          if (p.accum && cout_base + q < p.Cout) x += load_elem<OutT>(po + q);
+        }
+        if (p.act == FN2_ACT_LEAKY) x = leaky(x);
+        v[q] = x;
+      }
+      if (vec16 && cout_base + 15 < p.Cout) {
+        store16<OutT>(po, v);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (cout_base + q < p.Cout) store_elem<OutT>(po + q, v[q]);
+      }
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// stride-1 split-fp16 layers whose tiles stay inside image rows run the halo kernel; FN2_CONV_DBG bit 2048 = off (A/B)
+template <typename OutT>
+static bool launch_halo(const ConvArgs& a, int tile, int phases, hipStream_t s) {
+  if ((a.dbg & 2048) || a.stride != 1 || a.splitk != 1 || a.kg != 1 || !a.bp64 || (a.KW != 2 && a.KW != 3)) return false;
+  // one-round 128 x 64 grids (384..512 blocks) keep the 3-slot ring: two stages of DMA in flight beat the smaller
+  // stream there (conv3_1 at batch 4: ring 0.196 ms per 3 launches, halo 0.213)
+  if (tile == 128 && a.bp64 == 2 && !(a.dbg & 4096)) return false;
+  const int bp = tile == 128 ? 64 : 128;
+  if (a.OW % bp != 0 || a.M % bp != 0) return false;
+  dim3 block(256);
+#define FN2_HALO(GY, ...)                                                                         \
+  do {                                                                                            \
+    dim3 grid(a.M / bp, GY, phases);                                                              \
+    if (conv_name_sink().buf)                                                                     \
+      snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_halo_kernel<%s, %s, %d>",       \
+               is_x2<OutT>::value ? "fn2::x2_t" : "float", #__VA_ARGS__, a.KW);                    \
+    else if (a.KW == 3) hipLaunchKernelGGL((conv_halo_kernel<OutT, __VA_ARGS__, 3>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((conv_halo_kernel<OutT, __VA_ARGS__, 2>), grid, block, 0, s, a);      \
+  } while (0)
+  if (tile == 128) FN2_HALO(a.cout_pad / 128, 2, 2, 2, 1);
+  else if (tile == 64) FN2_HALO(a.cout_pad / 64, 1, 4, 2, 1);
+  else FN2_HALO(a.cout_pad / 32, 1, 4, 1, 1);
+#undef FN2_HALO
+  return true;
+}
+
+template <typename T> static const char* type_name();
+template <> const char* type_name<float>() { return "float"; }
+template <> const char* type_name<bf16_t>() { return "__bf16"; }
+template <> const char* type_name<f16_t>() { return "_Float16"; }
+template <> const char* type_name<x2_t>() { return "fn2::x2_t"; }
+
+ConvNameSink& conv_name_sink() {
+  static thread_local ConvNameSink sink{nullptr, 0};
+  return sink;
+}
+
 template <typename T, typename OutT>
 static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   const int z = phases * a.splitk;
@@ -554,7 +779,10 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
 #define FN2_LAUNCH2(GX, GY, THREADS, ...)                                                              \
   do {                                                                                                 \
     dim3 grid(GX, GY, z);                                                                              \
-    if (m16) hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, __VA_ARGS__, is_x2<T>::value>), grid, dim3(THREADS), 0, s, a); \
+    if (conv_name_sink().buf)                                                                          \
+      snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_igemm2_kernel<%s, %s, %s, %s>", type_name<T>(), \
+               type_name<OutT>(), #__VA_ARGS__, m16 ? "true" : "false");                              \
+    else if (m16) hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, __VA_ARGS__, is_x2<T>::value>), grid, dim3(THREADS), 0, s, a); \
     else hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, __VA_ARGS__, false>), grid, dim3(THREADS), 0, s, a);            \
   } while (0)
   if (tile == 128 && a.bp64 && a.kg == 3) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 768, 2, 2, 2, 1, 2, 3);
@@ -587,7 +815,11 @@ int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, i
     if (out_dtype == FN2_F16) return launch2<f16_t, f16_t>(a, tile, phases, s);
     return launch2<f16_t, float>(a, tile, phases, s);
   }
-  if (out_dtype == FN2_F16X2) return launch2<x2_t, x2_t>(a, tile, phases, s);
+  if (out_dtype == FN2_F16X2) {
+    if (launch_halo<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_halo"); return FN2_OK; }
+    return launch2<x2_t, x2_t>(a, tile, phases, s);
+  }
+  if (launch_halo<float>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_halo"); return FN2_OK; }
   return launch2<x2_t, float>(a, tile, phases, s);
 }
 

@@ -39,6 +39,11 @@ __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float
   store_vec<OutT, 4>(p, v);
 }
 
+// Name sink: while set (fn2_conv2d_kernel_name), the launchers write the instantiation they would launch -- as
+// rocprofv3 prints it, without the "void fn2::" prefix and the argument list -- and launch nothing.
+struct ConvNameSink { char* buf; int cap; };
+ConvNameSink& conv_name_sink();
+
 // conv2.hip: the fast path.  Returns FN2_ERR_UNSUPPORTED when (dtype, tile) has no instantiation.
 int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s);
 // true when the fast kernel covers this geometry (then the packed weight must use the permuted-64 row order)

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "fn2_conv2d_plan": (_i, [_i, _i, _i, C.POINTER(Fn2ConvPlan)]),
     "fn2_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(Fn2ConvDesc)]),
     "fn2_conv2d": (_i, [C.POINTER(Fn2ConvDesc), _p]),
+    "fn2_conv2d_kernel_name": (_i, [C.POINTER(Fn2ConvDesc), C.c_char_p, _i]),
     "fn2_augment_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fn2_flow_augmentation_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fn2_flow_head_gather": (_i, [_p, _i, _p, _p, _i, _i, _i, _p]),

@@ -148,6 +148,7 @@ class Engine:
         self.outputs = self._build()
         self._check_variables(strict)
         self._alloc_workspace()
+        self._resolve_kernel_names()
 
     # ------------------------------------------------------------------ buffers / views
     def _buf(self, name, n, h, w, c, dtype=None, stem=False):
@@ -438,6 +439,16 @@ class Engine:
         self._op(name, self.lib.fn2_resize_bilinear_f32, _hip.ptr(src_f32), _hip.ptr(dst), n, h, w, c, self.H,
                  self.W, C.c_float(scale))
         return dst
+
+    def _resolve_kernel_names(self):
+        """Ask the library which instantiation each fn2_conv2d launch takes (tile, ring, K groups, halo: decided in
+        conv.hip / conv2.hip from the geometry, the workspace and the tuning knobs) -- the per-kernel tables of the
+        bench and the PMC traffic lookup then carry the names rocprofv3 reports."""
+        buf = C.create_string_buffer(256)
+        for i, (name, fn, args) in enumerate(self.ops):
+            if fn is self.lib.fn2_conv2d:
+                if self.lib.fn2_conv2d_kernel_name(args[0], buf, 256) == 0 and buf.value:
+                    self.kernel_of[i] = buf.value.decode()
 
     def _alloc_workspace(self):
         """One fp32 split-K scratch buffer per branch, shared by the branch's layers (its launches are ordered)."""

@@ -185,6 +185,11 @@ int fn2_conv2d_plan(int in_dtype, int cin_pad, int cout, fn2_conv_plan* plan);
  * one buffer of the maximum over layers can be shared by all launches on a stream. */
 int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d);
 int fn2_conv2d(const fn2_conv_desc* d, void* stream);
+/* The device kernel (template instantiation, as rocprofv3 prints it without "void fn2::" and the argument list) that
+ * fn2_conv2d would launch for this descriptor under the current tuning knobs -- the tile / ring / K-group / halo choice is
+ * made inside the library; profiles and the bench's per-kernel table name launches by it.  "" for the paths that do
+ * not report (generic kernel, flow heads).  Launches nothing. */
+int fn2_conv2d_kernel_name(const fn2_conv_desc* desc, char* name, int cap);
 
 /* Flow head (predict_flowN: 3x3, stride 1, pad 1, 2 outputs; flownet_s.py:54-56) as a GEMM: run fn2_conv2d as a
  * 1x1 convolution with 18 outputs t[pix][tap*2+co] (weight w1x1[ci][tap*2+co] = w[ky][kx][ci][co]) into an fp32
