@@ -28,6 +28,7 @@
 #include "conv_common.h"
 
 #include <type_traits>
+#include <algorithm>
 #include <utility>
 
 #ifndef FN2_X2_ORDER
@@ -723,6 +724,162 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent short-K kernel for the 3x3 stems at full resolution (FlowNetSD conv0, the fusion net's fuse_conv0: 6 / 11
+// input channels -> 64, flownet_sd.py:29, flownet2.py:61): as kind-2 row-run convolutions their whole K is NST = 3
+// stages, so in the generic kernel a block spends its life in the prologue (per-lane pixel arithmetic), three
+// dependent DMA round trips and the epilogue -- 6144 blocks of that at batch 4.  Here a block keeps the 64 x K weight
+// matrix in LDS for its whole life (fetched once, not once per pixel tile) and walks pixel tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ...: ALL the stages of the next tile are in flight under the current tile's MFMAs and
+// stores.  One block of four waves per CU (120 KB of LDS), 64 cout x 128 pixel tiles as conv_igemm2<.., 1, 4, 2, 1>.
+template <typename OutT, int NST>
+__global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p, const int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = x2_t;
+  constexpr int ESZ = 4;
+  constexpr int BC = 64, BP = 128, TCN = 2;
+  __shared__ uint4 ldsA[NST][BC * 8];
+  __shared__ uint4 ldsB[2][NST][BP * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = pixel quarter wp (WC = 1, WP = 4)
+  const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
+  const v4i_t rsrc_w = make_rsrc(p.wgt, (int)(p.cout_pad * wrow_bytes));
+  const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
+  const int lrow = lane >> 3, lphys = lane & 7;
+  const int spt = p.cin_chunks >> 3;  // lines per run
+  // stage s: channel line sc = s / KH of kernel row ky = s % KH (the K order of conv_igemm2_kernel: line outer, row inner)
+  // ---- weights: once
+#pragma unroll
+  for (int st = 0; st < NST; ++st) {
+    const int sc = st / p.KH, ky = st - sc * p.KH;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave * 16 + j * 8 + lrow;
+      const unsigned woff = (unsigned)row * wrow_bytes + (unsigned)((lphys ^ ((row >> 1) & 7)) * 16);
+      dma16(rsrc_w, &ldsA[st][(wave * 16 + j * 8) * 8], woff, (ky * spt + sc) * 128);
+    }
+  }
+  auto issue_B = [&](int tile, int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 32 + j * 8 + lrow;
+      const int m = tile * BP + row;
+      const bool v = m < p.M && tile < ntiles;
+      const int mm = v ? m : 0;
+      const int n = mm / (p.OH * p.OW);
+      const int rem = mm - n * (p.OH * p.OW);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int roff = (((n * p.H + oy * p.stride) * p.W + ox * p.stride) * p.in_cs + p.in_c0) * ESZ +
+                       (lphys ^ ((row >> 1) & 7)) * 16;
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const int sc = st / p.KH, ky = st - sc * p.KH;
+        const int toff = (ky * p.W * p.in_cs) * ESZ + sc * 128;
+        dma16(rsrc_x, &ldsB[buf][st][(wave * 32 + j * 8) * 8], v ? (unsigned)(roff + toff) : kOobOffset, 0);
+      }
+    }
+  };
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  OutT* out = reinterpret_cast<OutT*>(p.out);
+  const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
+  float bias[TCN][16];
+#pragma unroll
+  for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = tc * 32 + fh * 16 + q;
+      bias[tc][q] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+
+  int tile = blockIdx.x, cur = 0;
+  issue_B(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+    issue_B(tile + gridDim.x, cur ^ 1);  // every stage of the next tile (zeros past the last one)
+    f32x16 acc[TCN];
+#pragma unroll
+    for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[tc][q] = 0.f;
+#if FN2_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const uint4* A = &ldsA[st][fr * 8];
+      const uint4* B = &ldsB[cur][st][(wave * 32 + fr) * 8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
+        const uint4 bh = B[chh], bl = B[chl];
+#pragma unroll
+        for (int tc = 0; tc < TCN; ++tc) {
+          const uint4 ah = A[tc * 32 * 8 + chh], al = A[tc * 32 * 8 + chl];
+          acc[tc] = mfma_32x32x16<f16_t>(al, bh, acc[tc]);
+          acc[tc] = mfma_32x32x16<f16_t>(ah, bl, acc[tc]);
+          acc[tc] = mfma_32x32x16<f16_t>(ah, bh, acc[tc]);
+        }
+      }
+    }
+#if FN2_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    const int m = tile * BP + wave * 32 + fr;
+    if (m < p.M) {
+      const int n = m / (p.OH * p.OW);
+      const int rem = m - n * (p.OH * p.OW);
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+#pragma unroll
+      for (int tc = 0; tc < TCN; ++tc) {
+        const int cout_base = tc * 32 + fh * 16;
+        OutT* po = out + (((size_t)n * p.out_H + oy) * p.out_W + ox) * p.out_cs + p.out_c0 + cout_base;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float x = acc[tc][q] * p.out_scale + bias[tc][q];
+          if (p.act == FN2_ACT_LEAKY) x = leaky(x);
+          v[q] = x;
+        }
+        if (vec16 && cout_base + 15 < p.Cout) {
+          store16<OutT>(po, v);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (cout_base + q < p.Cout) store_elem<OutT>(po + q, v[q]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// kind-2 stems with at most 4 stages and at most 64 output channels; FN2_CONV_DBG bit 8192 = off (A/B)
+template <typename OutT>
+static bool launch_stem(const ConvArgs& a, int tile, int phases, hipStream_t s) {
+  if ((a.dbg & 8192) || tile != 64 || phases != 1 || a.deconv || a.KW != 1 || a.splitk != 1 || a.accum ||
+      a.ksteps < 1 || a.ksteps > 4 || a.cout_pad != 64)
+    return false;
+  const int ntiles = cdiv(a.M, 128);
+  if (ntiles < 512) return false;  // the persistent form needs a few tiles per CU to amortise the weight fill
+  const char* e = getenv("FN2_STEM_BLOCKS");
+  const int blocks = std::min(ntiles, e ? atoi(e) : 256);
+  if (conv_name_sink().buf) {
+    snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_stem_kernel<%s, %d>",
+             is_x2<OutT>::value ? "fn2::x2_t" : "float", a.ksteps);
+    return true;
+  }
+  switch (a.ksteps) {
+    case 1: hipLaunchKernelGGL((conv_stem_kernel<OutT, 1>), dim3(blocks), dim3(256), 0, s, a, ntiles); break;
+    case 2: hipLaunchKernelGGL((conv_stem_kernel<OutT, 2>), dim3(blocks), dim3(256), 0, s, a, ntiles); break;
+    case 3: hipLaunchKernelGGL((conv_stem_kernel<OutT, 3>), dim3(blocks), dim3(256), 0, s, a, ntiles); break;
+    default: hipLaunchKernelGGL((conv_stem_kernel<OutT, 4>), dim3(blocks), dim3(256), 0, s, a, ntiles); break;
+  }
+  return true;
+}
+
 // stride-1 split-fp16 layers whose tiles stay inside image rows run the halo kernel; FN2_CONV_DBG bit 2048 = off (A/B)
 template <typename OutT>
 static bool launch_halo(const ConvArgs& a, int tile, int phases, hipStream_t s) {
@@ -816,6 +973,7 @@ int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, i
     return launch2<f16_t, float>(a, tile, phases, s);
   }
   if (out_dtype == FN2_F16X2) {
+    if (launch_stem<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_stem"); return FN2_OK; }
     if (launch_halo<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_halo"); return FN2_OK; }
     return launch2<x2_t, x2_t>(a, tile, phases, s);
   }
