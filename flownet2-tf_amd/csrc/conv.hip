@@ -336,6 +336,48 @@ __global__ void __launch_bounds__(256) flow_head_kernel(const ConvArgs p) {
     const float* wf1 = wf0 + (size_t)p.ksteps * 4 * CH;
     const int groups = p.cin_chunks >> 1;
     const int nitems = 9 * groups;
+    if (p.dbg & 16384) {
+      // block per pixel (small maps: the 6x8 .. 24x32 levels, 192..3072 pixels at batch 4): the four waves split the
+      // 9 x C/8 items of the pixel and the partial sums meet in LDS -- four times the loads in flight per pixel of
+      // the wave-per-pixel form below, whose single wave walks up to 18 dependent iterations
+      __shared__ float part[4][2];
+      const int wv = threadIdx.x >> 6;
+      for (long m = blockIdx.x; m < p.M; m += gridDim.x) {
+        const int x = (int)(m % p.W), y = (int)((m / p.W) % p.H);
+        const size_t nb = (size_t)(m / p.W / p.H) * p.H * p.W;
+        float a0 = 0.f, a1 = 0.f;
+        for (int q = threadIdx.x; q < nitems; q += 256) {
+          const int tap = q / groups, gi = q - tap * groups;
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int iy = y + ky - 1, ix = x + kx - 1;
+          if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+          const uint4* src = reinterpret_cast<const uint4*>(in + (nb + (size_t)iy * p.W + ix) * p.in_cs + p.in_c0 + gi * 8);
+          float xv[8];
+          join8(src[0], src[1], xv);
+          const float* u = wf0 + (size_t)q * 8;
+          const float* v = wf1 + (size_t)q * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            a0 += xv[j] * u[j];
+            a1 += xv[j] * v[j];
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          a0 += __shfl_xor(a0, off, 64);
+          a1 += __shfl_xor(a1, off, 64);
+        }
+        if (lane == 0) { part[wv][0] = a0; part[wv][1] = a1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float* po = out + (size_t)m * p.out_cs + p.out_c0;
+          po[0] = (part[0][0] + part[1][0] + part[2][0] + part[3][0]) * p.out_scale + (p.bias ? p.bias[0] : 0.f);
+          po[1] = (part[0][1] + part[1][1] + part[2][1] + part[3][1]) * p.out_scale + (p.bias ? p.bias[1] : 0.f);
+        }
+        __syncthreads();
+      }
+      return;
+    }
     for (long m = wave; m < p.M; m += nwaves) {
       const int x = (int)(m % p.W), y = (int)((m / p.W) % p.H);
       const size_t nb = (size_t)(m / p.W / p.H) * p.H * p.W;
@@ -897,7 +939,13 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (is_flow_head(d)) {
-    const int blocks = grid_for((long)a.M * 64, 256);
+    int blocks = grid_for((long)a.M * 64, 256);
+    if (d->in.dtype == FN2_F16X2 && a.M <= 4096 && !(a.dbg & 32768)) {  // block per pixel on the small maps
+      a.dbg |= 16384;
+      blocks = a.M;
+    } else {
+      a.dbg &= ~16384;
+    }
     if (d->in.dtype == FN2_F32)
       hipLaunchKernelGGL(flow_head_kernel<float>, dim3(blocks), dim3(256), 0, s, a);
     else if (d->in.dtype == FN2_BF16)
