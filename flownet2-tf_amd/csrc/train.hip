@@ -859,6 +859,21 @@ int fn2_leaky_bwd(const fn2_tensor* y, const fn2_tensor* g, float* db, void* str
   return FN2_OK;
 }
 
+// bias gradient of a narrow split-fp16 slice (c < 8: the two upsample_flow channels of a concat gradient buffer,
+// which carry a bias only in the FlowNet2 fusion net): lane per pixel, wave reduction, one atomic per wave and channel
+__global__ void __launch_bounds__(256) bias_grad_x2_narrow_kernel(const x2_t* __restrict__ g, float* __restrict__ db, long npix,
+                                                                  int c, int cs, int c0) {
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x)
+    for (int j = 0; j < c; ++j) acc[j] += load_elem<x2_t>(g + i * cs + c0 + j);
+  for (int j = 0; j < c; ++j) {
+    float v = acc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(db + j, v);
+  }
+}
+
 int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream) {
   FN2_REQUIRE(g && g->data && db, "bias_grad: null pointer");
   FN2_REQUIRE(g->dtype == FN2_F32 || g->dtype == FN2_F16X2, "bias_grad: fp32 or split-fp16 gradients");
@@ -867,6 +882,12 @@ int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream) {
   if (g->dtype == FN2_F16X2) {
     // linear layers with a bias in the split-fp16 trainer (FlowNetSD's interconvN): the LeakyReLU pass without the
     // activation factor
+    if (g->c < 8) {
+      hipLaunchKernelGGL(bias_grad_x2_narrow_kernel, dim3(grid_for(npix, 1024)), dim3(256), 0, st, (const x2_t*)g->data, db,
+                         npix, g->c, g->cs, g->c0);
+      FN2_CHECK_LAUNCH("bias_grad");
+      return FN2_OK;
+    }
     FN2_REQUIRE(g->c % 8 == 0 && g->cs % 8 == 0 && g->c0 % 8 == 0, "bias_grad: split-fp16 slices are group (8) aligned");
     const int l2x = gpb_log2_for(g->c / 8);
     const int sp = bias_splits(npix, l2x);

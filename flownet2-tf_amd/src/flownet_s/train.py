@@ -17,10 +17,14 @@ from ..training_schedules import LONG_SCHEDULE, SCHEDULES
 
 
 def unpack_weights(trainer):
-    """fp32 masters in the packed layouts -> {reference variable name: array in the reference layout}."""
+    """{reference variable name: array in the reference layout}: the fp32 masters of the trained layers (packed
+    layouts unpacked) over the frozen variables of the checkpoint the trainer was built from (the networks in front of
+    the last one in FlowNetCS / CSS, CSS and SD in FlowNet2), optimizer slots left out."""
     from ..trainer import _index_hwio
-    out = {}
-    for rec in trainer.eng.layers:
+    slots = ("/Adam", "/Adam_1")
+    out = {k: np.asarray(v) for k, v in trainer.host_weights.items()
+           if k.endswith(("/weights", "/biases")) and not k.endswith(slots)}
+    for rec in trainer.layers:
         name = f"{rec['scope']}/{rec['name']}"
         flat = rec["master"].cpu().numpy().reshape(-1)
         if rec["kind"] == "upflow":

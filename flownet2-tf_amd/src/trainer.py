@@ -74,10 +74,21 @@ class FlowNetSTrainer:
         self.loss_scale = 16384.0 if self.x2 else 1.0
         self.code = _hip.FN2_F16X2 if self.x2 else F32
         self.host_weights = weights
-        if model not in ("FlowNetS", "FlowNetSD", "FlowNetS_interp"):
-            raise ValueError("the trainer covers the networks without correlation / flow_warp: FlowNetS, FlowNetSD, "
-                             "FlowNetS_interp")
+        # What the reference's Net.train optimises per model (net.py:1316-1323 builds self.model(..., trainable=True)):
+        #   FlowNetS / SD / S_interp  the whole network;
+        #   FlowNetCS / CSS           the LAST FlowNetS only -- the networks in front are built trainable=False
+        #                             (flownet_cs.py:18, flownet_css.py:18) and feed it flow_warp / brightness-error
+        #                             inputs, so no gradient passes through flow_warp;
+        #   FlowNet2                  the fusion network only (flownet2.py:22-23: CSS and SD trainable=False), with the
+        #                             single-scale loss of flownet2.py:107-116.
+        # FlowNetC itself (gradients through the correlation and the shared towers) is not covered.
+        scopes = {"FlowNetS": "FlowNetS", "FlowNetSD": "FlowNetSD", "FlowNetS_interp": "FlowNetS",
+                  "FlowNetCS": "FlowNetCS/FlowNetS", "FlowNetCSS": "FlowNetCSS/FlowNetS", "FlowNet2": "FlowNet2"}
+        if model not in scopes:
+            raise ValueError("the trainer covers FlowNetS, FlowNetSD, FlowNetS_interp, the last network of FlowNetCS / "
+                             "FlowNetCSS and the fusion network of FlowNet2")
         self.model = model
+        self.train_scope = scopes[model]
         # hard-flow-example mining of FlowNetS_interp.loss (flownet_s_interp.py:159-254, utils.py:227-339): '' plain
         # AEPE, 'hard' the top hard_examples_perc % EPE pixels of the batch weighted (1 + lambda), 'edges' every pixel
         # weighted 1 + lambda * edge map (given per batch)
@@ -87,6 +98,14 @@ class FlowNetSTrainer:
         self.lambda_w, self.hard_perc = float(lambda_weight), float(hard_examples_perc)
         # label scale of the loss: 0.05 * gt for FlowNetS (flownet_s.py:123), 20 * gt for FlowNetSD (flownet_sd.py:122)
         self.gt_scale = 20.0 if model == "FlowNetSD" else 0.05
+        # {prediction name: loss weight}: the five scales of FlowNetS.loss through compute_weighted_loss (weights / 5,
+        # flownet_s.py:122-161); FlowNet2.loss is the plain average_endpoint_error of predict_flow0 against the
+        # UNSCALED ground truth (flownet2.py:107-116)
+        self.loss_terms = {"predict_flow%d" % lvl: wgt / 5.0 for lvl, wgt in LOSS_WEIGHTS.items()}
+        if model == "FlowNet2":
+            self.loss_terms, self.gt_scale = {"predict_flow0": 1.0}, 1.0
+            if self.hfem:
+                raise ValueError("hard-flow-example mining belongs to FlowNetS_interp")
         self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False)
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
@@ -135,7 +154,8 @@ class FlowNetSTrainer:
         self.base_of = {b.untyped_storage().data_ptr(): b for b in eng.bufs.values()}
         self.gbufs = {}
         self.gcode = {}  # gradient buffer -> fn2_dtype of the activation buffer it mirrors
-        layers = eng.layers
+        # trainable layers: those of the trained scope, in forward order (everything in front of them is frozen)
+        layers = self.layers = [rec for rec in eng.layers if rec["scope"] == self.train_scope]
         for rec in layers:
             # a bias the checkpoint does not define (FlowNetS_interp's heads, flownet_s_interp.py:86-95) is the engine's
             # constant zero vector, not a variable: no gradient, no Adam state, not saved
@@ -197,7 +217,7 @@ class FlowNetSTrainer:
         of its first (earliest-forward) layer has been enqueued.  ~40 MB buckets keep the xGMI ring
         bandwidth-bound.  self.buckets[i] = (index into bwd_ops after which it is complete, arena slice)."""
         offs, off = {}, 0
-        for rec in self.eng.layers:
+        for rec in self.layers:
             lo = off
             off += _round_up(rec["master"].numel(), 4)
             if rec.get("b") is not None:
@@ -318,6 +338,8 @@ class FlowNetSTrainer:
         self.keep.append(vg)
         ops = [(self.lib.fn2_upsample_flow_bwd, (C.byref(vg), _hip.ptr(pf), _hip.ptr(rec["w"]), _hip.ptr(self._gbuf(pf)),
                                                  _hip.ptr(rec["dw"]), 1))]
+        if rec.get("b") is not None:  # the fusion net's fuse_upsample_flow2to1 / 1to0 carry a bias (flownet2.py:70-73, :86-89)
+            ops.append((self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"]))))
         self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
 
     def backward_launches(self):
@@ -401,19 +423,19 @@ class FlowNetSTrainer:
                 device=self.dev, dtype=torch.float32)
             if edges_dev.ndim == 3:
                 edges_dev = edges_dev[..., None]
-        for lvl, wgt in LOSS_WEIGHTS.items():
-            pred = eng.outputs["predict_flow%d" % lvl]
+        for pname, wgt in self.loss_terms.items():
+            pred = eng.outputs[pname]
             n, h, w, _ = pred.shape
             label = torch.empty_like(pred)
             _hip.check(self.lib.fn2_downsample_f32(_hip.ptr(gts), _hip.ptr(label), n, self.H, self.W, 2, h, w, s))
             pw = self._pixel_weights(pred, label, edges_dev) if self.hfem else None
             if pw is None:
                 _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
-                                                      _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, self.loss_scale, s))
+                                                      _hip.ptr(self.loss_dev), n, h, w, wgt, self.loss_scale, s))
             else:
                 _hip.check(self.lib.fn2_epe_loss_grad_weighted(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(pw),
                                                                _hip.ptr(self._gbuf(pred)), _hip.ptr(self.loss_dev), n, h, w,
-                                                               wgt / 5.0, self.loss_scale, s))
+                                                               wgt, self.loss_scale, s))
             self.keep_label = (label, pw)
         # ---- backward
         from .dist import allreduce_bucket_async
@@ -571,13 +593,13 @@ class FlowNetSTrainer:
             self.loss_dev.zero_()
             eng.launch()
             torch.mul(self.gt, self.gt_scale, out=self._gts)
-            for lvl, wgt in LOSS_WEIGHTS.items():
-                pred = eng.outputs["predict_flow%d" % lvl]
+            for pname, wgt in self.loss_terms.items():
+                pred = eng.outputs[pname]
                 n, h, w, _ = pred.shape
-                label = self._labels[lvl]
+                label = self._labels[pname]
                 _hip.check(self.lib.fn2_downsample_f32(_hip.ptr(self._gts), _hip.ptr(label), n, self.H, self.W, 2, h, w, s))
                 _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
-                                                      _hip.ptr(self.loss_dev), n, h, w, wgt / 5.0, self.loss_scale, s))
+                                                      _hip.ptr(self.loss_dev), n, h, w, wgt, self.loss_scale, s))
         if seg < nseg:
             lo = 0 if seg == 0 else self._seg_ends[seg - 1] + 1
             # (the filter gradients as a parallel path of the graph -- they need only the layer's finished output
@@ -604,9 +626,9 @@ class FlowNetSTrainer:
         # one segment per gradient bucket when the gradients are exchanged, else a single backward segment
         self._seg_ends = [i for i, _ in self.buckets] if world_size() > 1 else [len(self.bwd_ops) - 1]
         self._gts = torch.empty_like(self.gt)
-        self._labels = {lvl: torch.empty_like(self.eng.outputs["predict_flow%d" % lvl]) for lvl in LOSS_WEIGHTS}
-        for lvl in LOSS_WEIGHTS:
-            self._gbuf(self.eng.outputs["predict_flow%d" % lvl])  # allocate outside the capture
+        self._labels = {pname: torch.empty_like(self.eng.outputs[pname]) for pname in self.loss_terms}
+        for pname in self.loss_terms:
+            self._gbuf(self.eng.outputs[pname])  # allocate outside the capture
         self._hyper = torch.zeros(5, dtype=torch.float32, device=self.dev)
         self._hyper_host = torch.zeros(5, dtype=torch.float32).pin_memory()
         self._build_adam_tables()

@@ -30,7 +30,7 @@ def _leaky(x, positive=None):
 
 
 def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS", l2=0.0, act_grads=None, signs=None,
-                             model="FlowNetS", add_hfem="", lambda_w=2.0, perc_hfem=50, edges=None):
+                             model="FlowNetS", add_hfem="", lambda_w=2.0, perc_hfem=50, edges=None, stacked=None):
     """Returns (loss, {variable name: gradient in the reference layout}, predictions).  l2 > 0 adds the slim
     regulariser 0.5*l2*|W|^2 of the slim.conv2d weights to the loss (and so l2*W to their gradients).
     act_grads: optional dict, filled with {layer name: dLoss/d(layer output), NHWC} for debugging.
@@ -66,6 +66,10 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
     a = torch.tensor(np.asarray(input_a, np.float64)).permute(0, 3, 1, 2)
     b = torch.tensor(np.asarray(input_b, np.float64)).permute(0, 3, 1, 2)
     x = torch.cat([a, b], 1)
+    if stacked is not None:
+        # the last FlowNetS of FlowNetCS / CSS: its 12-channel input [a | b | warped | 0.05 flow | brightness error]
+        # (flownet_cs.py:21-36) comes from networks built trainable=False -- a constant of the differentiation
+        x = torch.tensor(np.asarray(stacked, np.float64)).permute(0, 3, 1, 2)
     sd = model == "FlowNetSD"  # flownet_sd.py:14-119: all-3x3 encoder with conv0 at full resolution, interconvN heads
     if sd:
         c0 = conv(x, "conv0")
@@ -116,6 +120,40 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
         act_grads.update({k + "/value": v.detach().permute(0, 2, 3, 1).numpy() for k, v in acts.items()})
     out = {f"predict_flow{l}": p.detach().permute(0, 2, 3, 1).numpy() for l, p in preds.items()}
     return float(loss.detach()), grads, out
+
+
+def fusion_loss_and_grads(weights, fusion_input, gt_flow, scope="FlowNet2", signs=None):
+    """The trainable part of FlowNet2 (flownet2.py:50-116): the fusion network on its 11-channel input (a constant:
+    CSS and SD are built trainable=False, :22-23) and FlowNet2.loss = average_endpoint_error(downsample(flow, size of
+    predict_flow0), predict_flow0) -- unscaled ground truth, weight 1.  The four transposed convs carry biases.
+    Returns (loss, {variable: gradient in the reference layout}, predict_flow0 NHWC)."""
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in weights.items()
+         if k.startswith(scope + "/fuse_") or k.startswith(scope + "/predict_flow")}
+
+    def conv(x, name, stride=1, act=True):
+        y = F.conv2d(x, P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1), P[f"{scope}/{name}/biases"], stride=stride, padding=1)
+        return _leaky(y, None if signs is None else signs.get(name)) if act else y
+
+    def deconv(x, name, act=True):
+        y = F.conv_transpose2d(x, P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1), P[f"{scope}/{name}/biases"],
+                               stride=2, padding=1)
+        return _leaky(y, None if signs is None else signs.get(name)) if act else y
+
+    x = torch.tensor(np.asarray(fusion_input, np.float64)).permute(0, 3, 1, 2)
+    f0 = conv(x, "fuse_conv0")
+    f1_1 = conv(conv(f0, "fuse_conv1", 2), "fuse_conv1_1")
+    f2_1 = conv(conv(f1_1, "fuse_conv2", 2), "fuse_conv2_1")
+    pf2 = conv(f2_1, "predict_flow2", act=False)
+    cat1 = torch.cat([f1_1, deconv(f2_1, "fuse_deconv1"), deconv(pf2, "fuse_upsample_flow2to1", act=False)], 1)
+    pf1 = conv(conv(cat1, "fuse_interconv1", act=False), "predict_flow1", act=False)
+    cat0 = torch.cat([f0, deconv(cat1, "fuse_deconv0"), deconv(pf1, "fuse_upsample_flow1to0", act=False)], 1)
+    pf0 = conv(conv(cat0, "fuse_interconv0", act=False), "predict_flow0", act=False)
+    gt = np.asarray(gt_flow, np.float32)
+    label = torch.tensor(ops.downsample(gt, (pf0.shape[2], pf0.shape[3])).astype(np.float64)).permute(0, 3, 1, 2)
+    loss = torch.sqrt(((pf0 - label) ** 2).sum(1)).sum() / x.shape[0]
+    loss.backward()
+    grads = {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}
+    return float(loss.detach()), grads, pf0.detach().permute(0, 2, 3, 1).numpy()
 
 
 def adam_update(w, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):

@@ -370,6 +370,105 @@ def test_flownet_s_interp_gradients_match_oracle(mode):
     assert worst < (2e-5 if mode != "hard" else 2e-3), worst
 
 
+def _interior(buf, pad, c, x2):
+    """Interior (without the baked zero border) of a stem input buffer as float NHWC."""
+    v = buf.cpu().numpy()
+    if x2:
+        from src import weights as W
+        v = W.join_f16x2(v.view(np.float16))
+    return v[:, pad:v.shape[1] - pad, pad:v.shape[2] - pad, :c].astype(np.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,dtype", [("FlowNetCS", "f32"), ("FlowNetCSS", "f16x2")])
+def test_stacked_networks_train_their_last_network(model, dtype):
+    """Net.train on FlowNetCS / CSS optimises the LAST FlowNetS only: the networks in front are built trainable=False
+    (flownet_cs.py:18, flownet_css.py:18).  Loss and every gradient of that network against the float64 oracle fed
+    the same 12-channel stacked input; nothing in front of it is a parameter or moves under Adam."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights(model, 5)
+    a, b, gt = data(1, 128, 128, 1)
+    tr = FlowNetSTrainer(wts, 1, 128, 128, dtype=dtype, model=model)
+    scope = tr.train_scope
+    assert all(r["scope"] == scope for r in tr.layers) and len(tr.layers) == 23
+    assert all(p["name"].startswith(scope + "/") for p in tr.params)
+    loss = float(tr.forward_backward(a, b, gt).item())
+    tag = "CS/S" if model == "FlowNetCS" else "CSS/S"
+    stacked = _interior(tr.eng.bufs[tag + "/stack"], 3, 12, tr.x2)
+    signs = {k: v for k, v in device_signs(tr).items()}
+    signs = {r["name"]: signs[r["name"]] for r in tr.layers if r["kind"] != "upflow" and r["act"]}
+    for r in tr.layers:  # device_signs keys by layer name: take the trained network's buffers
+        if r["kind"] != "upflow" and r["act"]:
+            buf, c0, c = r["dst"]
+            vals = buf.cpu().numpy()
+            if tr.x2:
+                vals = W.join_f16x2(vals.view(np.float16))
+            signs[r["name"]] = np.sign(vals[..., c0:c0 + c]).astype(np.int8)
+    want_loss, grads, _ = reft.flownet_s_loss_and_grads(wts, a, b, gt, scope=scope, signs=signs, stacked=stacked)
+    assert abs(loss - want_loss) < 2e-5 * abs(want_loss), (loss, want_loss)
+    worst = 0.0
+    for rec in tr.layers:
+        name = f"{rec['scope']}/{rec['name']}"
+        got = rec["dw"].cpu().numpy() / np.float32(tr.loss_scale)
+        want = (grads[name + "/weights"].astype(np.float32).reshape(-1) if rec["kind"] == "upflow"
+                else packed_grad(rec, grads[name + "/weights"]).reshape(-1))
+        worst = max(worst, np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+        if rec.get("b") is not None:
+            gb, wb = rec["db"].cpu().numpy() / np.float32(tr.loss_scale), grads[name + "/biases"]
+            worst = max(worst, np.abs(gb - wb).max() / (np.abs(wb).max() + 1e-12))
+    assert worst < 2e-5, worst
+    # one Adam step: frozen variables come back unchanged, trained ones moved
+    from src.flownet_s import train as cli
+    tr.apply_gradients()
+    back = cli.unpack_weights(tr)
+    assert set(back) == set(wts)
+    for k, v in wts.items():
+        if k.startswith(scope + "/"):
+            assert k.endswith("/biases") or np.abs(back[k] - v).max() > 0, k
+        else:
+            assert np.array_equal(back[k], v), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_flownet2_trains_its_fusion_network(dtype):
+    """Net.train on FlowNet2 optimises the fusion network only (CSS and SD trainable=False, flownet2.py:22-23) under
+    FlowNet2.loss (flownet2.py:107-116): unscaled ground truth against predict_flow0, weight 1.  Loss, filter and bias
+    gradients -- the four transposed convs' biases included -- against the float64 oracle fed the same fusion input."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNet2", 5)
+    a, b, gt = data(1, 64, 64, 3)
+    gt = (gt * 0.05).astype(np.float32)  # FlowNet2's predict_flow0 is in pixels of flow / 1: keep the residuals O(1)
+    tr = FlowNetSTrainer(wts, 1, 64, 64, dtype=dtype, model="FlowNet2")
+    assert [r["name"] for r in tr.layers][:2] == ["fuse_conv0", "fuse_conv1"] and len(tr.layers) == 14
+    loss = float(tr.forward_backward(a, b, gt).item())
+    x11 = _interior(tr.eng.bufs["F2/fusion_in"], 1, 11, tr.x2)
+    signs = {}
+    for r in tr.layers:
+        if r["kind"] != "upflow" and r["act"]:
+            buf, c0, c = r["dst"]
+            vals = buf.cpu().numpy()
+            if tr.x2:
+                vals = W.join_f16x2(vals.view(np.float16))
+            signs[r["name"]] = np.sign(vals[..., c0:c0 + c]).astype(np.int8)
+    want_loss, grads, _ = reft.fusion_loss_and_grads(wts, x11, gt, signs=signs)
+    assert abs(loss - want_loss) < 2e-5 * abs(want_loss), (loss, want_loss)
+    worst, nbias_t = 0.0, 0
+    for rec in tr.layers:
+        name = f"{rec['scope']}/{rec['name']}"
+        got = rec["dw"].cpu().numpy() / np.float32(tr.loss_scale)
+        want = (grads[name + "/weights"].astype(np.float32).reshape(-1) if rec["kind"] == "upflow"
+                else packed_grad(rec, grads[name + "/weights"]).reshape(-1))
+        worst = max(worst, np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+        assert rec.get("b") is not None, name   # every fusion layer has a bias (flownet2.py:50-57)
+        gb, wb = rec["db"].cpu().numpy() / np.float32(tr.loss_scale), grads[name + "/biases"]
+        worst = max(worst, np.abs(gb - wb).max() / (np.abs(wb).max() + 1e-12))
+        nbias_t += rec["kind"] in (1, "upflow")
+    assert nbias_t == 4 and worst < 2e-5, worst
+
+
 @pytest.mark.gpu
 def test_flownet_s_interp_gradients_with_deconv_biases():
     """FlowNetS_interp(no_deconv_biases=False) (flownet_s_interp.py:84-126): predict_flowN AND deconvN carry (trainable)
