@@ -67,7 +67,7 @@ def _round_up(x, m):
 
 class Engine:
     def __init__(self, model, weights, batch, height, width, dtype="f32", device=None, heads_as_gemm=True,
-                 no_deconv_biases=None, strict=True, uint8_inputs=False):
+                 no_deconv_biases=None, strict=True, uint8_inputs=False, plain_stems=False):
         """uint8_inputs: the plan starts with two table look-up passes that turn uint8 image bytes (set_inputs_u8) into
         the fp32 [0,1] images -- Net.adapt_x's `/ 255.0` (net.py:338-345) after the host-to-device copy instead of
         before it, byte-identical, a quarter of the bytes over the host link.
@@ -144,6 +144,9 @@ class Engine:
         # flow heads as 1x1 GEMM (18 partial outputs per pixel) + gather; the trainer keeps the dot-product
         # head, whose natural-order weight its backward kernels read
         self.heads_as_gemm = heads_as_gemm
+        # plain_stems (the trainer): FlowNetC's conv1 as the plain 7x7 stride-2 row-run convolution on the padded
+        # 3-channel images instead of the space-to-depth form, so that its packed weight is the reference variable
+        self.plain_stems = bool(plain_stems)
         self._head_t = None
         self.outputs = self._build()
         self._check_variables(strict)
@@ -551,13 +554,21 @@ class Engine:
         cats = self._alloc_cats(tag, N)
         # both towers' images as 2x2 space-to-depth super-pixels with pad(.., 3) baked in (:30-34): the 7x7
         # stride-2 conv1 then runs as a 4x4 stride-1 row-run convolution over 16-channel super-pixels
-        x2 = self._buf(f"{tag}/images", 2 * N, (H + 6) // 2, (W_ + 6) // 2, 16, stem=True)
-        v = self._v(x2, 16, 0)
-        self.keep.append(v)
-        self._op(f"{tag}/pack_a", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_a), N, H, W_, C.byref(v), 0, 3)
-        self._op(f"{tag}/pack_b", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_b), N, H, W_, C.byref(v), N, 3)
         c1 = self._buf(f"{tag}/conv1", 2 * N, H // 2, W_ // 2, 64)
-        self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64), s2d=True)
+        if self.plain_stems:
+            x2 = self._buf(f"{tag}/images", 2 * N, H + 6, W_ + 6, 3, stem=True)
+            v = self._v(x2, 3, 0)
+            self.keep.append(v)
+            self._op(f"{tag}/pack_a", self.lib.fn2_pack_image, _hip.ptr(self.in_a), N, C.byref(v), 0, 3)
+            self._op(f"{tag}/pack_b", self.lib.fn2_pack_image, _hip.ptr(self.in_b), N, C.byref(v), N, 3)
+            self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64))
+        else:
+            x2 = self._buf(f"{tag}/images", 2 * N, (H + 6) // 2, (W_ + 6) // 2, 16, stem=True)
+            v = self._v(x2, 16, 0)
+            self.keep.append(v)
+            self._op(f"{tag}/pack_a", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_a), N, H, W_, C.byref(v), 0, 3)
+            self._op(f"{tag}/pack_b", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_b), N, H, W_, C.byref(v), N, 3)
+            self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64), s2d=True)
         c2b = self._buf(f"{tag}/conv_b_2", N, H // 4, W_ // 4, 128)
         M, T = self._branch, (4 if (self._lanes_on and self._lane_mask & 16) else self._branch)  # second tower (and conv_redir) on lane 4
         self._sync(T, M)
@@ -577,6 +588,8 @@ class Engine:
         tn = _TNAME[self.dtype_name]
         self._op(f"{tag}/correlation", self.lib.fn2_correlation_fused, C.byref(va), C.byref(vb), C.byref(vo), 20, 2,
                  _hip.ACT_LEAKY, kernel=self._corr_kernel_name(tn, H // 8))  # correlation(a3, b3, 1, 20, 1, 2, 20) + LeakyReLU, :40-41
+        # pseudo-layer for the trainer: the cost volume has no parameters but passes gradients to both towers
+        self.layers.append(dict(scope=scope, name="correlation", kind="corr", fa=c3a, fb=c3b, dst=(net, 32, 441)))
         self.layer_flops.append((f"{scope}/correlation", 2.0 * N * (H // 8) * (W_ // 8) * 441 * 256))
         # a and b read once, the 441 displacement channels written once, in the reference's fp32 terms
         # (11.71 MB per sample at 48 x 64)

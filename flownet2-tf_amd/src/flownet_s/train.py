@@ -25,6 +25,8 @@ def unpack_weights(trainer):
     out = {k: np.asarray(v) for k, v in trainer.host_weights.items()
            if k.endswith(("/weights", "/biases")) and not k.endswith(slots)}
     for rec in trainer.layers:
+        if rec["kind"] == "corr" or rec.get("shared_with") is not None:
+            continue
         name = f"{rec['scope']}/{rec['name']}"
         flat = rec["master"].cpu().numpy().reshape(-1)
         if rec["kind"] == "upflow":

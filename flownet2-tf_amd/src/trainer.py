@@ -81,12 +81,17 @@ class FlowNetSTrainer:
         #                             inputs, so no gradient passes through flow_warp;
         #   FlowNet2                  the fusion network only (flownet2.py:22-23: CSS and SD trainable=False), with the
         #                             single-scale loss of flownet2.py:107-116.
-        # FlowNetC itself (gradients through the correlation and the shared towers) is not covered.
-        scopes = {"FlowNetS": "FlowNetS", "FlowNetSD": "FlowNetSD", "FlowNetS_interp": "FlowNetS",
+        #   FlowNetC                  the whole network: the towers share conv1-3 (reuse=True, flownet_c.py:34-37: one
+        #                             variable, gradients of both towers summed) and the gradient passes through the
+        #                             correlation (CorrelationGrad, correlation.py:17-35); fp32 only -- the op surface of
+        #                             the correlation gradient is fp32 as the reference's.
+        scopes = {"FlowNetS": "FlowNetS", "FlowNetSD": "FlowNetSD", "FlowNetS_interp": "FlowNetS", "FlowNetC": "FlowNetC",
                   "FlowNetCS": "FlowNetCS/FlowNetS", "FlowNetCSS": "FlowNetCSS/FlowNetS", "FlowNet2": "FlowNet2"}
         if model not in scopes:
-            raise ValueError("the trainer covers FlowNetS, FlowNetSD, FlowNetS_interp, the last network of FlowNetCS / "
-                             "FlowNetCSS and the fusion network of FlowNet2")
+            raise ValueError("the trainer covers FlowNetS, FlowNetSD, FlowNetS_interp, FlowNetC, the last network of "
+                             "FlowNetCS / FlowNetCSS and the fusion network of FlowNet2")
+        if model == "FlowNetC" and dtype != "f32":
+            raise ValueError("FlowNetC trains in dtype 'f32' (the correlation gradient op is fp32)")
         self.model = model
         self.train_scope = scopes[model]
         # hard-flow-example mining of FlowNetS_interp.loss (flownet_s_interp.py:159-254, utils.py:227-339): '' plain
@@ -106,7 +111,7 @@ class FlowNetSTrainer:
             self.loss_terms, self.gt_scale = {"predict_flow0": 1.0}, 1.0
             if self.hfem:
                 raise ValueError("hard-flow-example mining belongs to FlowNetS_interp")
-        self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False)
+        self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False, plain_stems=True)
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
         self.schedule, self.eps = schedule, eps
@@ -125,8 +130,12 @@ class FlowNetSTrainer:
             self.gbufs[key] = torch.zeros_like(base)
         g = self.gbufs[key]
         self.gcode[g.data_ptr()] = self.eng._code(buf)
-        if buf.shape[0] != g.shape[0]:  # batch slice of a 2N buffer (not used by FlowNetS)
-            raise NotImplementedError
+        if buf.shape[0] != g.shape[0]:  # batch slice of a 2N buffer (FlowNetC's towers): the same rows of the mirror
+            base = self.base_of[key]
+            row = base.stride(0) * base.element_size()
+            n0 = (buf.data_ptr() - base.data_ptr()) // row
+            g = g[n0:n0 + buf.shape[0]]
+            self.gcode[g.data_ptr()] = self.eng._code(buf)
         return g
 
     def _view(self, buf, c, c0):
@@ -164,7 +173,22 @@ class FlowNetSTrainer:
         # ---- parameters and one flat gradient / moment arena (single all-reduce, single memset)
         params = []  # (tensor, l2 flag)
         self.fwd_copies = []  # f16x2 trainer: (split-fp16 forward weight, fp32 master, scale)
+        first_of = {}
         for rec in layers:
+            if rec["kind"] == "corr":
+                continue
+            key = f"{rec['scope']}/{rec['name']}"
+            if key in first_of:
+                # a second launch of the same variable (FlowNetC's second tower, reuse=True): one parameter; the
+                # forward of this launch reads the first launch's tensors, its gradients add into the same slices
+                first = first_of[key]
+                rec["shared_with"] = first
+                rec["master"] = first["master"]
+                rec["w"], rec["desc"].wgt = first["w"], first["w"].data_ptr()
+                if first.get("b") is not None:
+                    rec["b"], rec["desc"].bias = first["b"], first["b"].data_ptr()
+                continue
+            first_of[key] = rec
             reg = rec["kind"] in (0, 2)  # slim.conv2d weights (heads included); deconv / upsample / biases are not
             rec["master"] = self._master(rec)
             if rec["master"] is not rec["w"]:
@@ -194,6 +218,8 @@ class FlowNetSTrainer:
         # map bias tensors to their grads
         bias_grad = {p["w"].data_ptr(): p["g"] for p in self.params}
         for rec in layers:
+            if rec.get("shared_with") is not None:
+                rec["dw"] = rec["shared_with"]["dw"]
             if rec.get("b") is not None:
                 rec["db"] = bias_grad[rec["b"].data_ptr()]
 
@@ -201,7 +227,9 @@ class FlowNetSTrainer:
         self.bwd_ops = []
         self.gathers = []
         for rec in reversed(layers):
-            if rec["kind"] == "upflow":
+            if rec["kind"] == "corr":
+                self._plan_corr(rec)
+            elif rec["kind"] == "upflow":
                 self._plan_upflow(rec)
             elif rec["cout"] == 2:
                 self._plan_head(rec)
@@ -219,9 +247,10 @@ class FlowNetSTrainer:
         offs, off = {}, 0
         for rec in self.layers:
             lo = off
-            off += _round_up(rec["master"].numel(), 4)
-            if rec.get("b") is not None:
-                off += _round_up(rec["b"].numel(), 4)
+            if rec["kind"] != "corr" and rec.get("shared_with") is None:  # (those own no slice of the arena)
+                off += _round_up(rec["master"].numel(), 4)
+                if rec.get("b") is not None:
+                    off += _round_up(rec["b"].numel(), 4)
             offs[f"{rec['scope']}/{rec['name']}"] = (lo, off)
         total, target = off, off / float(n_buckets)
         self.buckets, hi, acc = [], total, 0
@@ -329,6 +358,36 @@ class FlowNetSTrainer:
         vdx = self._view(gx, sc, sc0)
         self.keep.append(vdx)
         ops.append((self.lib.fn2_head_bwd_data, (_hip.ptr(dpf), _hip.ptr(rec["master"]), C.byref(vdx), rec["cin_pad"], rec["kpad"])))
+        self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
+
+    def _plan_corr(self, rec):
+        """Backward of correlation + LeakyReLU (flownet_c.py:40-41): the LeakyReLU factor on the 441-channel slice of the
+        concat gradient, then CorrelationGrad (fn2_correlation_grad_f32, dense fp32 operands as the reference's op) into
+        scratch, added to the gradients of both towers' conv3 outputs (conv_redir adds its own share to tower a)."""
+        net, c0, c = rec["dst"]
+        a, b = rec["fa"], rec["fb"]
+        gnet, ga, gb = self._gbuf(net), self._gbuf(a), self._gbuf(b)
+        n, h, w, ch = a.shape
+        cpad = (net.shape[3] - c0) // 4 * 4  # the slice widened to the buffer's zero pad channels: 4-aligned for the pass
+        vy, vg = self._view(net, cpad, c0), self._view(gnet, cpad, c0)
+        gd = torch.empty((n, h, w, c), dtype=torch.float32, device=self.dev)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        self.keep += [vy, vg, gd, da, db]
+
+        def copy_grad(s):
+            gd.copy_(gnet[..., c0:c0 + c])
+            return 0
+
+        def add_grads(s):
+            ga.add_(da)
+            gb.add_(db)
+            return 0
+
+        ops = [(self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg), None)),
+               (copy_grad, ()),
+               (self.lib.fn2_correlation_grad_f32, (_hip.ptr(gd), _hip.ptr(a), _hip.ptr(b), _hip.ptr(da), _hip.ptr(db),
+                                                    n, h, w, ch, 1, 20, 1, 2, 20)),
+               (add_grads, ())]
         self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
 
     def _plan_upflow(self, rec):

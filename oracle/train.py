@@ -122,6 +122,70 @@ def flownet_s_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetS
     return float(loss.detach()), grads, out
 
 
+def correlation_torch(a, b, md=20, s2=2):
+    """The FlowNetC call of the correlation op (kernel 1, stride_1 1, pad = max_displacement; correlation_kernel.cu.cc:
+    45-110) on NCHW float64 torch tensors, differentiable: out[:, (p + r) * g + (o + r)] = mean_c a * shift(b, s2 p, s2 o)."""
+    r = md // s2
+    g = 2 * r + 1
+    n, c, h, w = a.shape
+    bp = F.pad(b, (md, md, md, md))
+    outs = []
+    for p in range(-r, r + 1):
+        for o in range(-r, r + 1):
+            y0, x0 = md + s2 * p, md + s2 * o
+            outs.append((a * bp[:, :, y0:y0 + h, x0:x0 + w]).sum(1) / c)
+    return torch.stack(outs, 1)
+
+
+def flownet_c_loss_and_grads(weights, input_a, input_b, gt_flow, scope="FlowNetC", signs=None):
+    """FlowNetC.model + FlowNetC.loss (flownet_c.py:15-170) in torch float64 with autograd: shared towers (one set of
+    conv1-3 variables, reuse=True at :34-37, so their gradients sum over both towers), correlation + LeakyReLU,
+    conv_redir, the FlowNetS-style rest and refinement; labels 0.05 * gt, five scales, / 5.  signs: {layer name (tower
+    b: name + '_b'; 'correlation'): sign of the layer output as the device computed it}, see flownet_s_loss_and_grads."""
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in weights.items()
+         if k.startswith(scope + "/")}
+
+    def sg(name):
+        return None if signs is None else signs.get(name)
+
+    def conv(x, name, stride=1, pad=1, act=True, tag=None):
+        y = F.conv2d(x, P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1), P.get(f"{scope}/{name}/biases"), stride=stride, padding=pad)
+        return _leaky(y, sg(tag or name)) if act else y
+
+    def deconv(x, name, act=True):
+        y = F.conv_transpose2d(x, P[f"{scope}/{name}/weights"].permute(3, 2, 0, 1), stride=2, padding=1)
+        return _leaky(y, sg(name)) if act else y
+
+    a = torch.tensor(np.asarray(input_a, np.float64)).permute(0, 3, 1, 2)
+    b = torch.tensor(np.asarray(input_b, np.float64)).permute(0, 3, 1, 2)
+    a2 = conv(conv(a, "conv1", 2, 3), "conv2", 2, 2)
+    a3 = conv(a2, "conv3", 2, 2)
+    b3 = conv(conv(conv(b, "conv1", 2, 3, tag="conv1_b"), "conv2", 2, 2, tag="conv2_b"), "conv3", 2, 2, tag="conv3_b")
+    cc = _leaky(correlation_torch(a3, b3), sg("correlation"))
+    net = torch.cat([conv(a3, "conv_redir", 1, 0), cc], 1)
+    c3_1 = conv(net, "conv3_1")
+    c4_1 = conv(conv(c3_1, "conv4", 2), "conv4_1")
+    c5_1 = conv(conv(c4_1, "conv5", 2), "conv5_1")
+    c6_1 = conv(conv(c5_1, "conv6", 2), "conv6_1")
+    preds = {6: conv(c6_1, "predict_flow6", act=False)}
+    cur = c6_1
+    for lvl, skip in zip((5, 4, 3, 2), (c5_1, c4_1, c3_1, a2)):
+        cur = torch.cat([skip, deconv(cur, f"deconv{lvl}"),
+                         deconv(preds[lvl + 1], f"upsample_flow{lvl + 1}to{lvl}", act=False)], 1)
+        preds[lvl] = conv(cur, f"predict_flow{lvl}", act=False)
+    n = a.shape[0]
+    gt = np.asarray(gt_flow, np.float32) * np.float32(0.05)
+    loss = 0.0
+    for lvl, wgt in LOSS_WEIGHTS.items():
+        p = preds[lvl]
+        label = torch.tensor(ops.downsample(gt, (p.shape[2], p.shape[3])).astype(np.float64)).permute(0, 3, 1, 2)
+        loss = loss + wgt * torch.sqrt(((p - label) ** 2).sum(1)).sum() / n
+    loss = loss / 5.0
+    loss.backward()
+    grads = {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}
+    return float(loss.detach()), grads, {f"predict_flow{l}": p.detach().permute(0, 2, 3, 1).numpy() for l, p in preds.items()}
+
+
 def fusion_loss_and_grads(weights, fusion_input, gt_flow, scope="FlowNet2", signs=None):
     """The trainable part of FlowNet2 (flownet2.py:50-116): the fusion network on its 11-channel input (a constant:
     CSS and SD are built trainable=False, :22-23) and FlowNet2.loss = average_endpoint_error(downsample(flow, size of

@@ -22,7 +22,7 @@ def device_signs(tr):
     """Branch of every LeakyReLU as the device took it (see oracle.train: the kink at 0)."""
     out = {}
     for rec in tr.eng.layers:
-        if rec["kind"] != "upflow" and rec["act"]:
+        if rec["kind"] not in ("upflow", "corr") and rec["act"]:
             buf, c0, c = rec["dst"]
             vals = buf.cpu().numpy()
             if tr.x2:  # split-fp16 activations live in fp32 containers: (hi, lo) halves per 8-channel group
@@ -396,9 +396,8 @@ def test_stacked_networks_train_their_last_network(model, dtype):
     loss = float(tr.forward_backward(a, b, gt).item())
     tag = "CS/S" if model == "FlowNetCS" else "CSS/S"
     stacked = _interior(tr.eng.bufs[tag + "/stack"], 3, 12, tr.x2)
-    signs = {k: v for k, v in device_signs(tr).items()}
-    signs = {r["name"]: signs[r["name"]] for r in tr.layers if r["kind"] != "upflow" and r["act"]}
-    for r in tr.layers:  # device_signs keys by layer name: take the trained network's buffers
+    signs = {}
+    for r in tr.layers:  # (layer names repeat across the sub-networks: take the trained network's buffers)
         if r["kind"] != "upflow" and r["act"]:
             buf, c0, c = r["dst"]
             vals = buf.cpu().numpy()
@@ -428,6 +427,68 @@ def test_stacked_networks_train_their_last_network(model, dtype):
             assert k.endswith("/biases") or np.abs(back[k] - v).max() > 0, k
         else:
             assert np.array_equal(back[k], v), k
+
+
+def test_oracle_torch_correlation_equals_numpy_correlation():
+    import torch
+    from oracle import ops as refo
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((2, 6, 9, 8)).astype(np.float32), rng.standard_normal((2, 6, 9, 8)).astype(np.float32)
+    want = refo.correlation(a, b, 1, 20, 1, 2, 20)
+    got = reft.correlation_torch(torch.tensor(a, dtype=torch.float64).permute(0, 3, 1, 2),
+                                 torch.tensor(b, dtype=torch.float64).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_flownet_c_gradients_match_oracle():
+    """FlowNetC trained as the reference's graph defines it (flownet_c.py:15-170): ONE set of conv1-3 variables for
+    both towers (gradients summed), the gradient through correlation + LeakyReLU (CorrelationGrad) into both towers,
+    conv_redir's share added to tower a.  Loss and every filter / bias gradient against the float64 autograd oracle."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetC", 5)
+    a, b, gt = data(2, 128, 128, 1)
+    tr = FlowNetSTrainer(wts, 2, 128, 128, dtype="f32", model="FlowNetC")
+    assert sum(1 for r in tr.layers if r.get("shared_with") is not None) == 2          # conv2, conv3 of tower b
+    assert len({p["name"] for p in tr.params}) == len(tr.params) == len(wts)           # one parameter per variable
+    loss = float(tr.forward_backward(a, b, gt).item())
+    signs, seen = {}, set()
+    for r in tr.layers:
+        if r["kind"] == "corr":
+            net, c0, c = r["dst"]
+            signs["correlation"] = np.sign(net.cpu().numpy()[..., c0:c0 + c]).astype(np.int8)
+        elif r["kind"] != "upflow" and r["act"]:
+            buf, c0, c = r["dst"]
+            vals = np.sign(buf.cpu().numpy()[..., c0:c0 + c]).astype(np.int8)
+            if r["name"] == "conv1":      # one 2N-batch launch: rows [0, N) tower a, [N, 2N) tower b
+                signs["conv1"], signs["conv1_b"] = vals[:2], vals[2:]
+            else:
+                signs[r["name"] + ("_b" if r["name"] in seen else "")] = vals
+            seen.add(r["name"])
+    want_loss, grads, _ = reft.flownet_c_loss_and_grads(wts, a, b, gt, signs=signs)
+    assert abs(loss - want_loss) < 2e-5 * abs(want_loss), (loss, want_loss)
+    worst = 0.0
+    for rec in tr.layers:
+        if rec["kind"] == "corr" or rec.get("shared_with") is not None:
+            continue
+        name = f"{rec['scope']}/{rec['name']}"
+        got = rec["dw"].cpu().numpy()
+        want = (grads[name + "/weights"].astype(np.float32).reshape(-1) if rec["kind"] == "upflow"
+                else packed_grad(rec, grads[name + "/weights"]).reshape(-1))
+        err = np.abs(got - want).max() / (np.abs(want).max() + 1e-12)
+        berr = 0.0
+        if rec.get("b") is not None:
+            gb, wb = rec["db"].cpu().numpy(), grads[name + "/biases"]
+            berr = np.abs(gb - wb).max() / (np.abs(wb).max() + 1e-12)
+        print("  %-28s filter %.2e  bias %.2e" % (name, err, berr))
+        worst = max(worst, err, berr)
+    assert worst < 2e-5, worst
+    # Adam moves the shared variables once, and both towers read the moved tensor
+    w_before = tr.layers[1]["master"].clone()
+    tr.apply_gradients()
+    second = next(r for r in tr.layers if r.get("shared_with") is not None and r["name"] == "conv2")
+    assert second["desc"].wgt == second["shared_with"]["w"].data_ptr() and not torch.equal(w_before, second["shared_with"]["master"])
 
 
 @pytest.mark.gpu
