@@ -252,7 +252,18 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the one
+            # JSON line by pointing fd 1 at stderr while the group forms
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
 
     if args.mode == "train":
         out = run_train(args, rank, world, dist)
