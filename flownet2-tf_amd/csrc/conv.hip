@@ -757,6 +757,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   if (d->out.dtype == FN2_F16X2) FN2_REQUIRE(d->out.cs % 8 == 0 && d->out.c0 % 8 == 0, "conv2d: split-fp16 views are group (8) aligned");
 
   ConvArgs& a = *out;
+  a.KH_KW_hint = 0;
   a.in = d->in.data; a.wgt = d->wgt; a.bias = d->bias; a.out = d->out.data;
   a.N = d->in.n; a.H = d->in.h; a.W = d->in.w; a.in_cs = d->in.cs; a.in_c0 = d->in.c0;
   a.cin_chunks = d->cin_pad / CH;
@@ -778,6 +779,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     FN2_REQUIRE(d->cin_pad >= d->kw * d->in.cs, "stem conv: run (cin_pad) shorter than kw*cs");
     FN2_REQUIRE(d->wgt_layout == 1, "stem conv: runs on the LDS-DMA kernel only (run must be whole 128-byte lines)");
     a.KH = d->kh; a.KW = 1; a.stride = d->stride; a.pad = 0;
+    a.KH_KW_hint = d->kw;
     a.OH = (d->in.h - d->kh) / d->stride + 1;
     a.OW = (d->in.w - d->kw) / d->stride + 1;
     FN2_REQUIRE(a.OH >= 1 && a.OW >= 1, "stem conv: kernel does not fit");
@@ -832,6 +834,15 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     FN2_REQUIRE(in_bytes < (1L << 31), "conv2d: input buffer >= 2 GiB is not addressable by the LDS-DMA kernel");
     FN2_REQUIRE((long)d->cout_pad * d->kpad * esz < (1L << 31), "conv2d: packed weight >= 2 GiB per phase");
     a.in_bytes = (int)in_bytes;
+  }
+  {
+    // order of the (pixel tile, cout tile) bands over the XCDs: fabric bytes ~ A min(8, X) + B with the pixel-major
+    // order (every XCD that holds a pixel tile pulls the weights), A + B min(8, Y) with the weight-major one
+    const double A = (double)d->cout_pad * d->kpad * esz, B = (double)d->in.n * d->in.h * d->in.w * d->in.cs * esz;
+    const long X = cdiv(M, 64), Y = cdiv(d->cout_pad, 128);
+    const char* e = getenv("FN2_WMAJOR");
+    const int mode = e ? atoi(e) : 2;
+    a.wmajor = mode == 2 ? (A * (double)(X < 8 ? X : 8) + B > A + B * (double)(Y < 8 ? Y : 8)) : mode;
   }
   a.bp64 = wants_bp64(a, tile, phases, d->wgt_layout) ? 1 : 0;
   // experiment (bit 64): weight-streaming 128-cout layers (the ones left on 128 x 128 + split-K) on 128 x 64 tiles
@@ -980,7 +991,7 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   else if (d->in.dtype == FN2_BF16) rc = launch_conv<bf16_t, float>(a, tile, phases, s);
   else if (d->out.dtype == FN2_F16) rc = launch_conv<f16_t, f16_t>(a, tile, phases, s);
   else rc = launch_conv<f16_t, float>(a, tile, phases, s);
-  if (rc || a.splitk == 1 || conv_name_sink().buf) return rc;
+  if (rc || a.splitk == 1 || conv_name_sink().buf || (a.dbg & 524288)) return rc;  // (524288: ablation, no finalize pass)
   const long npix = (long)a.N * a.out_H * a.out_W;
   const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
   if (d->out.dtype == FN2_F32)

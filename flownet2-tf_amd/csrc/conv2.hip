@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
   }
   const int kt0 = split * p.kper + grp;  // first stage of this K group
-  const int kt1 = min(p.ksteps, split * p.kper + p.kper);
+  const int kt1 = (FN2_CONV_ABLATE && (p.dbg & 1048576)) ? kt0 : min(p.ksteps, split * p.kper + p.kper);  // ablation: no K loop
   // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id
   // order, so with the plain mapping a pixel tile's vertical neighbours and its other cout tiles run on other
   // XCDs / much later: every 3x3 halo row and every extra cout tile re-read the activations from HBM.  Give
@@ -135,8 +135,16 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     const int NT = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
     const int xcd = L & 7, chunk = NT >> 3, rem = NT & 7;
     const int Lp = xcd * chunk + min(xcd, rem) + (L >> 3);
-    bx = Lp / (int)gridDim.y;
-    by = Lp - bx * (int)gridDim.y;
+    if (p.wmajor) {
+      // weight-streaming layers (the 6x8 / 12x16 levels: tens of MB of weights, under 2 MB of activations): the
+      // pixel tiles of one cout tile run side by side on one XCD, so a weight line crosses the fabric once instead
+      // of once per XCD that holds one of its pixel tiles; the small input is what gets re-read by every XCD
+      by = Lp / (int)gridDim.x;
+      bx = Lp - by * (int)gridDim.x;
+    } else {
+      bx = Lp / (int)gridDim.y;
+      by = Lp - bx * (int)gridDim.y;
+    }
   }
   const int m0 = bx * BP;
   const int c0 = by * BC;
@@ -247,6 +255,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 
   // one stage of MFMAs on the LDS object `lds`
   auto compute = [&](const uint4* lds) {
+    if (FN2_CONV_ABLATE && (p.dbg & 131072)) return;  // ablation: no LDS reads, no MFMAs
 #if FN2_SETPRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
@@ -429,6 +438,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
       }
   }
 
+  if (FN2_CONV_ABLATE && (p.dbg & 262144)) return;  // ablation: no epilogue
   if constexpr (M16) {
     // D of a 16 x 16 sub-tile: column (pixel) = lane & 15, rows (packed weight rows) 4 (lane >> 4) + j.  With the row
     // permutation of the 32 x 32 layout (packed row (r & 3) + 8 (r >> 2) + 4 h <-> cout 16 h + r) the four rows of a
@@ -856,6 +866,172 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p, const 
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-run stems from the RAW image row (kind 2: the first layer of every network on its pre-padded few-channel input;
+// flownet_s.py:39 conv1 7x7 s2 on 12 / 6 channels, flownet_c.py:30-34 as 4x4 s1 on 2x2 super-pixels, flownet_sd.py:29
+// conv0 and flownet2.py:61 fuse_conv0 3x3 s1).  In conv_igemm2_kernel a pixel's run of KW*cs channels is fetched as
+// whole 128-byte lines per OUTPUT pixel although neighbouring runs overlap by (KW - stride) / KW: conv1 of FlowNetS
+// moves 3.5 KB per output pixel and kernel row.  Here the block fetches the input row SEGMENT its 128 output pixels
+// read -- (127 stride + KW) pixels x cs channels, once per kernel row -- and the MFMA operand of output pixel r,
+// 8-channel group g is simply LDS slot (r stride) (cs / 4) + 2 g (+1 for the lo half): the run IS contiguous in the
+// raw image.  Slots are XOR-swizzled (slot ^ ((slot >> 4) & 15), applied to the DMA source and to the reads) so that 16
+// lanes at a stride of 2, 4 or 8 slots land on 16 different 16-byte slots of a bank row.  About half the L2 -> LDS
+// bytes of the line form for every stem (weights still move per 128-byte line of the run).
+// Tile 64 cout x 128 pixels of one output row; weights double-buffered per line, the segment per kernel row.
+template <typename OutT, int SPP>
+__global__ void __launch_bounds__(256) conv_rowrun_kernel(const ConvArgs p, const int npieces) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = x2_t;
+  constexpr int BC = 64, BP = 128, TCN = 2;
+  constexpr int MAXP = SPP == 4 ? 17 : 9;      // 1 KB pieces of a segment: 7x7 s2 on cs 16 reads 1048 slots, on cs 8 524
+  __shared__ uint4 ldsA[2][BC * 8];
+  __shared__ uint4 ldsB[2][MAXP * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* wgt = reinterpret_cast<const T*>(p.wgt);
+  const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {  // XCD-aware tile order (see conv_igemm2_kernel): vertical neighbours share KH - stride input rows
+    const int NT = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = L & 7, chunk = NT >> 3, rem = NT & 7;
+    const int Lp = xcd * chunk + min(xcd, rem) + (L >> 3);
+    bx = Lp / (int)gridDim.y;
+    by = Lp - bx * (int)gridDim.y;
+  }
+  const int m0 = bx * BP, c0 = by * BC;
+  const int tn = m0 / (p.OH * p.OW);
+  const int trem = m0 - tn * (p.OH * p.OW);
+  const int toy = trem / p.OW, tox = trem - toy * p.OW;   // the tile lies inside one output row
+
+  const v4i_t rsrc_w = make_rsrc(wgt, (int)(p.cout_pad * wrow_bytes));
+  const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
+  const int lrow = lane >> 3, lphys = lane & 7;
+  unsigned woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wave * 16 + j * 8 + lrow;
+    woff[j] = (unsigned)(c0 + row) * wrow_bytes + (unsigned)((lphys ^ ((row >> 1) & 7)) * 16);
+  }
+  // segment DMA: physical slot P of piece q <- logical slot P ^ ((P >> 4) & 15) of the row segment
+  const int nslots = ((BP - 1) * p.stride + p.KH_KW_hint) * SPP;  // slots holding real pixels
+  const int seg0 = (((tn * p.H + toy * p.stride) * p.W + tox * p.stride) * p.in_cs + p.in_c0) * 4;  // byte offset at ky = 0
+  constexpr int NBW = (MAXP + 3) / 4;
+  unsigned boff[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int q = wave + 4 * j;
+    const int P = q * 64 + lane;
+    const int Ls = P ^ ((P >> 4) & 15);
+    boff[j] = (q < npieces && Ls < nslots) ? (unsigned)(seg0 + Ls * 16) : kOobOffset;
+  }
+  const int nl = p.cin_chunks >> 3;   // 128-byte lines per kernel row
+  auto issue_B = [&](int ky, uint4* lds) {
+    const int toff = ky * p.W * p.in_cs * 4;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int q = wave + 4 * j;
+      if (q < npieces) dma16(rsrc_x, &lds[q * 64], boff[j] == kOobOffset ? kOobOffset : boff[j] + (unsigned)toff, 0);
+    }
+  };
+  auto issue_A = [&](int ky, int l, uint4* lds) {   // weight k index = ky * run_pad + channel (pack_stem)
+    const int soff = (ky * nl + l) * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(rsrc_w, &lds[(wave * 16 + j * 8) * 8], woff[j], soff);
+  };
+
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  const int pslot = (wave * 32 + fr) * p.stride * SPP;   // first slot of this lane's pixel run
+  f32x16 acc[TCN];
+#pragma unroll
+  for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[tc][q] = 0.f;
+
+  issue_B(0, ldsB[0]);
+  issue_A(0, 0, ldsA[0]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int abuf = 0;
+  for (int ky = 0; ky < p.KH; ++ky) {
+    const uint4* lb = ldsB[ky & 1];
+    for (int l = 0; l < nl; ++l) {
+      if (l + 1 < nl) issue_A(ky, l + 1, ldsA[abuf ^ 1]);
+      else if (ky + 1 < p.KH) issue_A(ky + 1, 0, ldsA[abuf ^ 1]);
+      if (l == 0 && ky + 1 < p.KH) issue_B(ky + 1, ldsB[(ky + 1) & 1]);
+#if FN2_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      const uint4* A = &ldsA[abuf][fr * 8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
+        const int g = 4 * l + 2 * q + fh;               // 8-channel group of the run
+        const int sh = pslot + 2 * g, sl = sh + 1;
+        const uint4 bh = lb[sh ^ ((sh >> 4) & 15)], bl = lb[sl ^ ((sl >> 4) & 15)];
+#pragma unroll
+        for (int tc = 0; tc < TCN; ++tc) {
+          const uint4 ah = A[tc * 32 * 8 + chh], al = A[tc * 32 * 8 + chl];
+          acc[tc] = mfma_32x32x16<f16_t>(al, bh, acc[tc]);
+          acc[tc] = mfma_32x32x16<f16_t>(ah, bl, acc[tc]);
+          acc[tc] = mfma_32x32x16<f16_t>(ah, bh, acc[tc]);
+        }
+      }
+#if FN2_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      abuf ^= 1;
+    }
+  }
+
+  OutT* out = reinterpret_cast<OutT*>(p.out);
+  const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
+  const int ox = tox + wave * 32 + fr;
+#pragma unroll
+  for (int tc = 0; tc < TCN; ++tc) {
+    const int cout_base = c0 + tc * 32 + fh * 16;
+    OutT* po = out + (((size_t)tn * p.out_H + toy) * p.out_W + ox) * p.out_cs + p.out_c0 + cout_base;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float x = acc[tc][q] * p.out_scale + ((p.bias != nullptr && cout_base + q < p.Cout) ? p.bias[cout_base + q] : 0.f);
+      if (p.act == FN2_ACT_LEAKY) x = leaky(x);
+      v[q] = x;
+    }
+    if (vec16 && cout_base + 15 < p.Cout) {
+      store16<OutT>(po, v);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (cout_base + q < p.Cout) store_elem<OutT>(po + q, v[q]);
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// kind-2 stems on split fp16 whose 128-pixel tiles stay inside output rows; FN2_CONV_DBG bit 65536 = off (A/B)
+template <typename OutT>
+static bool launch_rowrun(const ConvArgs& a, int tile, int phases, hipStream_t s) {
+  if ((a.dbg & 65536) || tile != 64 || phases != 1 || a.deconv || a.KW != 1 || a.KH_KW_hint < 1 || a.splitk != 1 || a.accum)
+    return false;
+  if (a.OW % 128 != 0 || (a.in_cs != 8 && a.in_cs != 16)) return false;
+  const int spp = a.in_cs / 4;
+  const int nl = a.cin_chunks >> 3;
+  // slots read: the last pixel's run end, rounded up to whole 8-channel groups of whole lines
+  const int max_slot = 127 * a.stride * spp + 2 * (4 * nl - 1) + 1;
+  const int npieces = max_slot / 64 + 1;
+  if (npieces > (spp == 4 ? 17 : 9)) return false;
+  dim3 grid(a.M / 128, a.cout_pad / 64, 1), block(256);
+  if (conv_name_sink().buf) {
+    snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_rowrun_kernel<%s, %d>", is_x2<OutT>::value ? "fn2::x2_t" : "float", spp);
+    return true;
+  }
+  if (spp == 4) hipLaunchKernelGGL((conv_rowrun_kernel<OutT, 4>), grid, block, 0, s, a, npieces);
+  else hipLaunchKernelGGL((conv_rowrun_kernel<OutT, 2>), grid, block, 0, s, a, npieces);
+  return true;
+}
+
 // kind-2 stems with at most 4 stages and at most 64 output channels; FN2_CONV_DBG bit 8192 = off (A/B)
 template <typename OutT>
 static bool launch_stem(const ConvArgs& a, int tile, int phases, hipStream_t s) {
@@ -973,6 +1149,7 @@ int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, i
     return launch2<f16_t, float>(a, tile, phases, s);
   }
   if (out_dtype == FN2_F16X2) {
+    if (launch_rowrun<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_rowrun"); return FN2_OK; }
     if (launch_stem<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_stem"); return FN2_OK; }
     if (launch_halo<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_halo"); return FN2_OK; }
     return launch2<x2_t, x2_t>(a, tile, phases, s);

@@ -20,7 +20,9 @@ struct ConvArgs {
   int act;
   int deconv;   // 1: four output phases in blockIdx.z (transposed convolutions), output pixel (2m+a, 2m'+b)
   int ph_pad0, ph_pad1;  // tap origin of phase a = 0 / 1: input row = m - ph_pad + t
+  int wmajor;   // LDS-DMA kernel: XCD bands run over the pixel tiles of ONE cout tile (weight-streaming layers), see conv.hip
   int bp64;     // LDS-DMA kernel: half-width pixel tiles (128x64 / 64x128 / 32x128), see wants_bp64 in conv.hip
+  int KH_KW_hint;  // kind 2 (row-run stems): the real kernel width KW (KW itself is 1 there: a kernel row is one "tap"); else 0
   int kg;       // LDS-DMA kernel, 128 x 64 tiles: K groups per block (1, 2 or 3; conv2.hip), see build_args in conv.hip
   int accum;    // 1: out += result (fp32 outputs; gradient accumulation into shared buffers)
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0

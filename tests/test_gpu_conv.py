@@ -294,6 +294,53 @@ def test_stem_rowrun_conv(dtype, k, stride, cin, cs):
     np.testing.assert_allclose(got, want, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("k,stride,cin,cs,H,Wd,pad", [
+    (7, 2, 12, 16, 12, 512, 3),    # FlowNetS conv1 inside the stacks (flownet_s.py:39): 2 tiles per output row
+    (7, 2, 6, 8, 10, 256, 3),      # FlowNetS conv1 on a plain pair
+    (4, 1, 16, 16, 7, 259, 0),     # FlowNetC conv1 on 2x2 super-pixels (flownet_c.py:30-34)
+    (3, 1, 6, 8, 9, 256, 1),       # FlowNetSD conv0 (flownet_sd.py:29)
+    (3, 1, 11, 16, 9, 384, 1),     # fuse_conv0 (flownet2.py:61)
+])
+def test_stem_from_raw_row_segment(k, stride, cin, cs, H, Wd, pad):
+    """conv_rowrun_kernel (split fp16, output rows of whole 128-pixel tiles): the MFMA operand gathered from the raw
+    row segment in LDS equals the line form (conv_igemm2_kernel) and the oracle."""
+    from src import _hip, weights as W
+    lib = _hip.lib()
+    N, cout = 2, 64
+    x = rnd((N, H, Wd, cin), 40)
+    w = rnd((k, k, cin, cout), 41, (2.0 / (k * k * cin)) ** 0.5)
+    b = rnd((cout,), 42, 0.1)
+    want = refnn.conv2d(x, w, b, stride=stride, padding=pad, activation=refnn.leaky_relu)
+    xp = np.zeros((N, H + 2 * pad, Wd + 2 * pad, cs), np.float32)
+    xp[:, pad:pad + H, pad:pad + Wd, :cin] = x
+    if cs > cin:  # finite garbage in the padding channels meets zero weights
+        xp[..., cin:] = 3.0
+    xin = _to_dev(xp, "f16x2")
+    code = _CODE["f16x2"]
+    run = (k * cs + 31) // 32 * 32
+    plan = _hip.conv_plan(code, run, cout)
+    packed, cin_pad, cout_pad, kpad = W.pack_stem(w, cs, run, plan.cout_tile, plan.layout)
+    k2 = int(np.floor(np.log2(1024.0 / np.abs(packed).max())))
+    packed, scale = packed * 2.0 ** k2, 2.0 ** -k2
+    wdev = W.packed_to_device(packed, plan.wgt_dtype, "cuda")
+    bdev = torch.from_numpy(b).cuda()
+    oh, ow = want.shape[1], want.shape[2]
+    assert ow % 128 == 0
+    out = _to_dev(np.zeros((N, oh, ow, 64), np.float32), "f16x2")
+    d = _hip.Fn2ConvDesc()
+    d.inp, d.out = _hip.view(xin, cs, 0, code), _hip.view(out, cout, 0, code)
+    d.wgt, d.bias = wdev.data_ptr(), bdev.data_ptr()
+    d.kind, d.kh, d.kw, d.stride, d.pad, d.act = 2, k, k, stride, 0, 1
+    d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout, d.out_scale = cin_pad, cout_pad, kpad, plan.layout, scale
+    name = C.create_string_buffer(256)
+    _hip.check(lib.fn2_conv2d_kernel_name(C.byref(d), name, 256))
+    assert name.value.decode().startswith("conv_rowrun_kernel"), name.value
+    _hip.check(lib.fn2_conv2d(C.byref(d), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    got = _from_dev(out, code)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
 def test_upsample_flow_matches_oracle():
     from src import _hip
     lib = _hip.lib()

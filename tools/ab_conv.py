@@ -36,6 +36,14 @@ LAYERS = {  # name: (kind, k, stride, pad, cin, cout, N, H, W) -- FlowNetC batch
     "fuse_interconv1": ("conv", 3, 1, 1, 162, 32, 4, 192, 256),
     "fuse_deconv0": ("deconv", 4, 2, 1, 162, 16, 4, 192, 256),
     "fuse_conv1_1": ("conv", 3, 1, 1, 64, 128, 4, 192, 256),
+    # the weight-streaming levels at FlowNet2's batch 4
+    "conv5_b4": ("conv", 3, 2, 1, 512, 512, 4, 24, 32),
+    "conv5_1_b4": ("conv", 3, 1, 1, 512, 512, 4, 12, 16),
+    "conv6_b4": ("conv", 3, 2, 1, 512, 1024, 4, 12, 16),
+    "conv6_1_b4": ("conv", 3, 1, 1, 1024, 1024, 4, 6, 8),
+    "deconv5_b4": ("deconv", 4, 2, 1, 1024, 512, 4, 6, 8),
+    "deconv4_b4": ("deconv", 4, 2, 1, 1026, 256, 4, 12, 16),
+    "conv4_1_b4": ("conv", 3, 1, 1, 512, 512, 4, 24, 32),
     # long dispatches for counter / clock diagnostics
     "conv3_1_b64": ("conv", 3, 1, 1, 256, 256, 64, 48, 64),
 }
@@ -91,7 +99,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--variants", default="0,16")
-    ap.add_argument("--layers", default=",".join(k for k in LAYERS if not k.endswith("_b64")))
+    ap.add_argument("--layers", default=",".join(k for k in LAYERS if not k.endswith(("_b64", "_b4"))))
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--inner", type=int, default=5)
     ap.add_argument("--libs", default="", help="comma list of alternative builds of the library (tools/build_variant.sh); "

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../flownet2-tf_amd/csrc"
 name=$1; shift
 mkdir -p build/var_$name ../lib/variants
-for f in ops conv conv2 corr corr2 elem train aug hostio; do
+for f in $(ls *.hip | sed "s/\.hip$//"); do
   hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wno-unused-function $@ -c $f.hip -o build/var_$name/$f.o &
 done
 wait
