@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         float x = acc[t][pt][r] * p.out_scale + bias[t][r];
         if constexpr (sizeof(OutT) == 4) {
           if (p.accum && co + r < p.Cout) x += load_elem<OutT>(po + co + r);
+          if (co + r < p.Cout) x = act_grad<OutT>(p, out, po + co + r, co + r, x);
         }
         if (p.act == FN2_ACT_LEAKY) x = leaky(x);
         v[r] = x;
@@ -246,7 +247,8 @@ template <typename OutT>
 __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                               OutT* __restrict__ out, long npix, int ws_cs, int splitk,
                                                               int Cout, int out_cs, int out_c0, int act, int vec_ok,
-                                                              float out_scale, int accum) {
+                                                              float out_scale, int accum, const OutT* __restrict__ mask_y,
+                                                              int mask_c0, int mask_c1) {
   const int groups = ws_cs / 4;
   const long total = npix * groups;
   const size_t slab = (size_t)npix * ws_cs;
@@ -260,12 +262,29 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
     }
     float r[4] = {v.x, v.y, v.z, v.w};
     OutT* po = out + (size_t)pix * out_cs + out_c0 + co;
+    const bool full = vec_ok && co + 3 < Cout;
+    float old[4] = {0.f, 0.f, 0.f, 0.f}, yv[4] = {1.f, 1.f, 1.f, 1.f};
+    const bool mask = mask_y != nullptr && co < mask_c1 && co + 4 > mask_c0;  // fused LeakyReLU backward (act_grad, conv_common.h)
+    if constexpr (sizeof(OutT) == 4) {
+      if (full) {
+        if (accum) load4<OutT>(po, old);
+        if (mask) load4<OutT>(mask_y + (size_t)pix * out_cs + out_c0 + co, yv);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (co + j < Cout) {
+            if (accum) old[j] = load_elem<OutT>(po + j);
+            if (mask) yv[j] = load_elem<OutT>(mask_y + (size_t)pix * out_cs + out_c0 + co + j);
+          }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       r[j] *= out_scale;
       if (bias != nullptr && co + j < Cout) r[j] += bias[co + j];
       if constexpr (sizeof(OutT) == 4) {
-        if (accum && co + j < Cout) r[j] += load_elem<OutT>(po + j);
+        if (accum) r[j] += old[j];
+        if (mask && co + j >= mask_c0 && co + j < mask_c1) r[j] *= yv[j] > 0.f ? 1.f : (yv[j] < 0.f ? 0.1f : 0.55f);
       }
       if (act == FN2_ACT_LEAKY) r[j] = leaky(r[j]);
     }
@@ -813,6 +832,13 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     phases = 4;
   }
   a.accum = d->accumulate ? 1 : 0;
+  a.mask_y = d->act_grad_y; a.mask_c0 = d->act_grad_c0; a.mask_c1 = d->act_grad_c1;
+  if (a.mask_y != nullptr) {
+    FN2_REQUIRE(d->out.dtype == FN2_F32 || d->out.dtype == FN2_F16X2, "conv2d: act_grad_y needs an fp32 or split-fp16 output");
+    FN2_REQUIRE(d->act == FN2_ACT_NONE && d->kind != 2, "conv2d: act_grad_y goes with a linear gradient layer (kinds 0, 1, 3)");
+    FN2_REQUIRE(0 <= a.mask_c0 && a.mask_c0 < a.mask_c1 && a.mask_c1 <= d->out.c, "conv2d: act_grad channel range outside the output view");
+    FN2_REQUIRE(!is_flow_head(d), "conv2d: act_grad_y is not available on the flow-head path");
+  }
   if (a.accum) FN2_REQUIRE(d->out.dtype == FN2_F32 || d->out.dtype == FN2_F16X2,
                            "conv2d: accumulate needs an fp32 or split-fp16 output");
   const long M = (long)a.N * a.OH * a.OW;
@@ -996,16 +1022,16 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
   if (d->out.dtype == FN2_F32)
     hipLaunchKernelGGL(splitk_finalize_kernel<float>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (float*)a.out, npix,
-                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
+                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const float*)a.mask_y, a.mask_c0, a.mask_c1);
   else if (d->out.dtype == FN2_F16X2)
     hipLaunchKernelGGL(splitk_finalize_kernel<x2_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (x2_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const x2_t*)a.mask_y, a.mask_c0, a.mask_c1);
   else if (d->out.dtype == FN2_BF16)
     hipLaunchKernelGGL(splitk_finalize_kernel<bf16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (bf16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const bf16_t*)a.mask_y, a.mask_c0, a.mask_c1);
   else
     hipLaunchKernelGGL(splitk_finalize_kernel<f16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (f16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const f16_t*)a.mask_y, a.mask_c0, a.mask_c1);
   FN2_CHECK_LAUNCH("splitk_finalize");
   return FN2_OK;
 }

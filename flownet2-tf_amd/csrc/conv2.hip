@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
           float x = acc16[a][b][j] * p.out_scale + ((p.bias != nullptr && co + j < p.Cout) ? p.bias[co + j] : 0.f);
           if constexpr (sizeof(OutT) == 4) {
             if (p.accum && co + j < p.Cout) x += load_elem<OutT>(po + co + j);
+            if (co + j < p.Cout) x = act_grad<OutT>(p, out16, po + co + j, co + j, x);
           }
           if (p.act == FN2_ACT_LEAKY) x = leaky(x);
           v[j] = x;
@@ -526,13 +527,12 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
                  p.out_c0 + cout_base;
       float v[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float x = acc[tc][tp][q] * p.out_scale + bias[q];
-        if constexpr (sizeof(OutT) == 4) {  // fp32 and split-fp16 outputs can accumulate (gradient buffers)
-          if (p.accum && cout_base + q < p.Cout) x += load_elem<OutT>(po + q);
-        }
-        if (p.act == FN2_ACT_LEAKY) x = leaky(x);
-        v[q] = x;
+      for (int q = 0; q < 16; ++q) v[q] = acc[tc][tp][q] * p.out_scale + bias[q];
+      // fp32 and split-fp16 outputs can accumulate (gradient buffers) and take the fused LeakyReLU backward
+      accum_act_grad16<OutT>(p, out, po, cout_base, vec16 && cout_base + 15 < p.Cout, v);
+      if (p.act == FN2_ACT_LEAKY) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = leaky(v[q]);
       }
       if (vec16 && cout_base + 15 < p.Cout) {
         store16<OutT>(po, v);
@@ -714,13 +714,11 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
                  p.out_c0 + cout_base;
       float v[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float x = acc[tc][tp][q] * p.out_scale + bias[q];
-        if constexpr (sizeof(OutT) == 4) {
-          if (p.accum && cout_base + q < p.Cout) x += load_elem<OutT>(po + q);
-        }
-        if (p.act == FN2_ACT_LEAKY) x = leaky(x);
-        v[q] = x;
+      for (int q = 0; q < 16; ++q) v[q] = acc[tc][tp][q] * p.out_scale + bias[q];
+      accum_act_grad16<OutT>(p, out, po, cout_base, vec16 && cout_base + 15 < p.Cout, v);
+      if (p.act == FN2_ACT_LEAKY) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = leaky(v[q]);
       }
       if (vec16 && cout_base + 15 < p.Cout) {
         store16<OutT>(po, v);

@@ -32,8 +32,55 @@ struct ConvArgs {
   int ws_cs;   // Cout rounded up to 4
   float out_scale;  // accumulator scale before bias (power of two chosen by the weight packer)
   int in_bytes;  // byte size of the input buffer (LDS-DMA kernel: buffer descriptor num_records)
+  const void* mask_y;  // fused LeakyReLU backward (fn2_conv_desc.act_grad_y): forward activations laid out like `out`, or nullptr
+  int mask_c0, mask_c1;  // ... applied to channels [mask_c0, mask_c1) of the output view
   int dbg;     // FN2_CONV_DBG ablation bits (timing experiments only; results are wrong when set)
 };
+
+// Backward of LeakyReLU fused into the epilogue of the layer that completes a gradient slice: x is the finished
+// gradient wrt the activation OUTPUT at `elem`; the factor d/dx (0.55 x + 0.45 |x|) is read off the forward output y at
+// the same position of the mirrored buffer (1 for y > 0, 0.1 for y < 0, 0.55 at 0: train.hip, act_bias_bwd_kernel).
+template <typename OutT>
+__device__ __forceinline__ float act_grad(const ConvArgs& p, const OutT* out_base, const OutT* elem, int co, float x) {
+  if (p.mask_y != nullptr && co >= p.mask_c0 && co < p.mask_c1) {
+    const float y = load_elem<OutT>(reinterpret_cast<const OutT*>(p.mask_y) + (elem - out_base));
+    x *= y > 0.f ? 1.f : (y < 0.f ? 0.1f : 0.55f);
+  }
+  return x;
+}
+
+// The 16 consecutive couts [cout_base, cout_base + 16) of one pixel in an LDS-DMA kernel's epilogue: v (+)= what the
+// output holds (accumulate), then the fused LeakyReLU backward; `full`: all 16 inside the view and 32-byte aligned.
+template <typename OutT>
+__device__ __forceinline__ void accum_act_grad16(const ConvArgs& p, const OutT* out_base, const OutT* po, int cout_base,
+                                                 bool full, float (&v)[16]) {
+  if constexpr (sizeof(OutT) == 4) {
+    const bool mask = p.mask_y != nullptr && cout_base < p.mask_c1 && cout_base + 16 > p.mask_c0;
+    if (!p.accum && !mask) return;
+    if (full) {
+      if (p.accum) {
+        float o[16];
+        load16<OutT>(po, o);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] += o[q];
+      }
+      if (mask) {
+        float y[16];
+        load16<OutT>(reinterpret_cast<const OutT*>(p.mask_y) + (po - out_base), y);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (cout_base + q >= p.mask_c0 && cout_base + q < p.mask_c1) v[q] *= y[q] > 0.f ? 1.f : (y[q] < 0.f ? 0.1f : 0.55f);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (cout_base + q < p.Cout) {
+          if (p.accum) v[q] += load_elem<OutT>(po + q);
+          v[q] = act_grad<OutT>(p, out_base, po + q, cout_base + q, v[q]);
+        }
+    }
+  }
+}
 
 template <typename OutT>
 __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d) {

@@ -165,6 +165,25 @@ __device__ __forceinline__ void store16(T* p, const float* v) {
   }
 }
 
+// 16 consecutive elements as 16-byte loads (fp32 and split fp16: the types gradient buffers have)
+template <typename T>
+__device__ __forceinline__ void load16(const T* p, float* v) {
+  static_assert(sizeof(T) == 4, "load16: fp32 / split-fp16 tensors");
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  if constexpr (is_x2<T>::value) {
+    join8(a, b, v);
+    join8(c, d, v + 8);
+  } else {
+    const uint4 r[4] = {a, b, c, d};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[4 * i] = __uint_as_float(r[i].x); v[4 * i + 1] = __uint_as_float(r[i].y);
+      v[4 * i + 2] = __uint_as_float(r[i].z); v[4 * i + 3] = __uint_as_float(r[i].w);
+    }
+  }
+}
+
 // 16-bit matrix-core products on raw 16-byte operand chunks (8 elements of T)
 template <typename T>
 __device__ __forceinline__ f32x4 mfma_16x16x32(const uint4& a, const uint4& b, const f32x4& c);

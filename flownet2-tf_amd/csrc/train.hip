@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(256) head_bwd_data_kernel(const float* __restr
 // ---------------------------------------------------------------------------
 struct BwdwArgs {
   const float* dn; const float* sm; float* dw;
+  float* db;                           // bias gradient db[i] += sum_pix Dn[pix][i] (convolutions: Dn = dY), or nullptr
   int N, DH, DW_, dn_cs, dn_c0, Ci;   // dense tensor: [N, DH, DW] pixels, Ci channels of interest
   int SH, SW, sm_cs, sm_c0, Cj;       // sampled tensor
   int KH, KW, stride, pad;
@@ -580,6 +581,22 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
         }
     }
   };
+  // Bias gradient in the same pass (convolutions: Dn = dY): the blocks of tap 0, j tile 0 see every dense pixel of
+  // their (i tile, pixel range) exactly once; thread t sums channel t & 127 over 16 of a stage's 32 pixel rows.
+  const bool do_bias = p.db != nullptr && tap == 0 && j0 == 0;
+  float bsum = 0.f;
+  auto bias_stage = [&](const float (*lds)[PK * 128]) {
+    const int c = tid & 127, r0 = (tid >> 7) * 16;
+    if (!do_bias || c >= TI) return;
+    if constexpr (X2) {
+      const _Float16* h = reinterpret_cast<const _Float16*>(&lds[0][0]) + (c >> 3) * 16 + (c & 7);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum += (float)h[(r0 + r) * 256] + (float)h[(r0 + r) * 256 + 8];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum += lds[0][(r0 + r) * 128 + c];
+    }
+  };
   issue(0, lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -588,12 +605,20 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
   for (int st = 0; st < nstage2; st += 2) {
     issue(st + 1, lds1);
     compute(lds0);
+    bias_stage(lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st + 2 < nstage2) issue(st + 2, lds0);
     compute(lds1);
+    bias_stage(lds1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if (do_bias) {  // block-uniform: the two pixel halves of a channel meet in LDS (the stage buffers are free)
+    if (tid >= 128) lds0[0][tid - 128] = bsum;
+    __syncthreads();
+    const int c = tid;
+    if (tid < 128 && c < TI && i0 + c < p.Ci) atomicAdd(p.db + i0 + c, bsum + lds0[0][c]);
   }
   // D layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); (row, col) = (i, j), or (j, i) if SWAP
   float* base = p.dw + p.tap_base[tap];
@@ -743,6 +768,22 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
         }
     }
   };
+  // Bias gradient in the same pass (see bwd_filter_kernel); channel c of pixel row r: hi half-word (c & 7) of chunk
+  // 2 (c >> 3) ^ swz(r), lo of the chunk after it (before the swizzle)
+  const bool do_bias = p.db != nullptr && tap == 0 && j0 == 0;
+  float bsum = 0.f;
+  auto bias_stage = [&](const float (*lds)[PK * 128]) {
+    const int c = tid & 127, r0 = (tid >> 7) * 16;
+    if (!do_bias || c >= TI) return;
+    const char* base = reinterpret_cast<const char*>(&lds[0][0]) + (c & 7) * 2;
+    const int L = 2 * (c >> 3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + r, sw = (row & 1) | ((row & 2) << 2);
+      bsum += (float)*reinterpret_cast<const _Float16*>(base + row * 512 + (L ^ sw) * 16) +
+              (float)*reinterpret_cast<const _Float16*>(base + row * 512 + ((L + 1) ^ sw) * 16);
+    }
+  };
   issue(0, lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -750,12 +791,19 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
   for (int st = 0; st < nstage2; st += 2) {
     issue(st + 1, lds1);
     compute(lds0);
+    bias_stage(lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st + 2 < nstage2) issue(st + 2, lds0);
     compute(lds1);
+    bias_stage(lds1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if (do_bias) {
+    if (tid >= 128) lds0[0][tid - 128] = bsum;
+    __syncthreads();
+    if (tid < 128 && tid < TI && i0 + tid < p.Ci) atomicAdd(p.db + i0 + tid, bsum + lds0[0][tid]);
   }
   const int fr = lane & 31, fk = lane >> 5;
   float* base = p.dw + p.tap_base[tap];
@@ -1058,6 +1106,8 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
       }
   }
   a.dn = (const float*)dn->data; a.sm = (const float*)sm->data; a.dw = d->dw;
+  FN2_REQUIRE(d->db == nullptr || d->kind != 1, "bwd_filter: the fused bias gradient sums dy, the dense operand of convolutions only");
+  a.db = d->db;
   a.N = dn->n; a.DH = dn->h; a.DW_ = dn->w; a.dn_cs = dn->cs; a.dn_c0 = dn->c0; a.Ci = dn->c;
   a.SH = sm->h; a.SW = sm->w; a.sm_cs = sm->cs; a.sm_c0 = sm->c0; a.Cj = d->kind == 2 ? d->kw * sm->cs : sm->c;
   const long dnb = (long)dn->n * dn->h * dn->w * dn->cs * 4, smb = (long)sm->n * sm->h * sm->w * sm->cs * 4;

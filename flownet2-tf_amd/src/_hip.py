@@ -32,13 +32,14 @@ class Fn2ConvDesc(C.Structure):
     _fields_ = [("inp", Fn2Tensor), ("out", Fn2Tensor), ("wgt", C.c_void_p), ("bias", C.c_void_p),
                 ("kind", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("act", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
-                ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("act_grad_y", C.c_void_p), ("act_grad_c0", C.c_int32), ("act_grad_c1", C.c_int32)]
 
 
 class Fn2BwdwDesc(C.Structure):
     _fields_ = [("x", Fn2Tensor), ("dy", Fn2Tensor), ("dw", C.c_void_p), ("kind", C.c_int32), ("kh", C.c_int32),
                 ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("cin_pad", C.c_int32),
-                ("cout_pad", C.c_int32), ("kpad", C.c_int32), ("wgt_layout", C.c_int32)]
+                ("cout_pad", C.c_int32), ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("db", C.c_void_p)]
 
 
 _i, _p, _f = C.c_int, C.c_void_p, C.c_float

@@ -17,6 +17,7 @@ copies that the input-gradient convolutions read are refreshed once per step by 
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -226,7 +227,17 @@ class FlowNetSTrainer:
         # ---- per-layer backward launches, in reverse forward order
         self.bwd_ops = []
         self.gathers = []
-        for rec in reversed(layers):
+        self._act_ops = []
+        order = list(reversed(layers))
+        for i in range(len(order) - 1):
+            # a flow head and the transposed conv of the next level read the same tensor (predict_flowN and deconvN-1 on
+            # concatN / conv6_1); both add into its gradient.  The head goes first, so that the LAST writer of that
+            # gradient is a convolution, whose epilogue can apply the LeakyReLU factor (_fuse_act_grads)
+            a, b = order[i], order[i + 1]
+            if a["kind"] == 1 and b["kind"] == 0 and b.get("cout") == 2 and a["src"][0].data_ptr() == b["src"][0].data_ptr():
+                order[i], order[i + 1] = b, a
+        self.bwd_recs = order  # bwd_ops[i] is the backward of bwd_recs[i]
+        for rec in order:
             if rec["kind"] == "corr":
                 self._plan_corr(rec)
             elif rec["kind"] == "upflow":
@@ -235,9 +246,62 @@ class FlowNetSTrainer:
                 self._plan_head(rec)
             else:
                 self._plan_conv(rec)
+        self._fuse_act_grads()
         eng._alloc_workspace()  # the input-gradient convolutions share the split-K scratch buffer
         self.refresh_backward_weights()
         self._plan_buckets(4)
+
+    def _fuse_act_grads(self):
+        """LeakyReLU backward without its own pass over the tensor: when the last launch that adds into a layer's output
+        gradient is an input-gradient convolution (the next encoder layer's, the next level's transposed conv or
+        interconv), that launch multiplies the finished sums by the LeakyReLU factor in its epilogue
+        (fn2_conv_desc.act_grad_y) and the layer keeps only the bias-gradient reduction.  Everything else -- a slice
+        completed by a flow head's input gradient, ranges off the 16-channel grid of the epilogue, FN2_FUSE_ACT_GRAD=0
+        -- stays on fn2_leaky_bwd."""
+        self.fused_act = []
+        if os.environ.get("FN2_FUSE_ACT_GRAD", "1") == "0":
+            return
+        lib = self.lib
+
+        def writes(fn, args):
+            """[(first byte, end byte, c0, c)] a backward launch adds into (4-byte elements in every gradient buffer)."""
+            span = lambda v: (v.data, v.data + 4 * v.n * v.h * v.w * v.cs, v.c0, v.c)
+            if fn is lib.fn2_conv2d:
+                return [span(args[0]._obj.out)]
+            if fn is lib.fn2_head_bwd_data:
+                return [span(args[2]._obj)]
+            return list(getattr(fn, "writes", []))
+
+        for act in self._act_ops:
+            bi = act["block"]  # (names repeat: FlowNetC runs conv2 / conv3 once per tower)
+            vg, vy = act["vg"], act["vy"]
+            lo, hi = vg.c0, vg.c0 + vg.c
+            g0, g1 = vg.data, vg.data + 4 * vg.n * vg.h * vg.w * vg.cs
+            last = None
+            for bj in range(bi - 1, -1, -1):
+                for fn, args in reversed(self.bwd_ops[bj][1]):
+                    if any(b0 < g1 and g0 < b1 and c0 < hi and lo < c0 + c for b0, b1, c0, c in writes(fn, args)):
+                        last = (fn, args)
+                        break
+                if last is not None:
+                    break
+            if last is None or last[0] is not lib.fn2_conv2d:
+                continue
+            d = last[1][0]._obj
+            o = d.out
+            rel0, rel1 = lo - o.c0, hi - o.c0
+            if d.act_grad_y or rel0 < 0 or rel1 > o.c or rel0 % 16 or (rel1 % 16 and rel1 != o.c) or o.dtype != vy.dtype:
+                continue
+            if (o.data, o.n, o.h, o.w, o.cs) != (vg.data, vg.n, vg.h, vg.w, vg.cs):
+                continue  # the writer covers a batch slice only (FlowNetC's conv1 runs both towers as one 2N batch)
+            d.act_grad_y, d.act_grad_c0, d.act_grad_c1 = vy.data, rel0, rel1
+            ops = self.bwd_ops[bi][1]
+            assert ops[0][0] is lib.fn2_leaky_bwd
+            if act["db"] is not None:
+                ops[0] = (lib.fn2_bias_grad, (C.byref(vg), act["db"]))
+            else:
+                del ops[0]
+            self.fused_act.append(act["name"])
 
     def _plan_buckets(self, n_buckets):
         """Gradient exchange overlapped with backward: the arena is laid out in FORWARD layer order and backward
@@ -251,16 +315,19 @@ class FlowNetSTrainer:
                 off += _round_up(rec["master"].numel(), 4)
                 if rec.get("b") is not None:
                     off += _round_up(rec["b"].numel(), 4)
-            offs[f"{rec['scope']}/{rec['name']}"] = (lo, off)
+            offs[id(rec)] = (lo, off)  # (by layer, not by name: FlowNetC launches conv2 / conv3 once per tower)
         total, target = off, off / float(n_buckets)
-        self.buckets, hi, acc = [], total, 0
-        for i, (name, _) in enumerate(self.bwd_ops):
-            lo, _hi = offs[name]
-            acc = hi - lo
+        # (backward runs the layers in reverse forward order except that a flow head goes in front of the transposed
+        # conv that follows it in the forward pass: a tail is complete once the launches so far cover exactly it)
+        self.buckets, hi, done, tail = [], total, 0, total
+        assert len(self.bwd_recs) == len(self.bwd_ops)
+        for i, rec in enumerate(self.bwd_recs):
+            lo, up = offs[id(rec)]
+            done, tail = done + up - lo, min(tail, lo)
             last = i == len(self.bwd_ops) - 1
-            if acc >= target or last:
-                self.buckets.append((i, self.grad_arena[lo:hi]))
-                hi = lo
+            if total - tail == done and (hi - tail >= target or last):
+                self.buckets.append((i, self.grad_arena[tail:hi]))
+                hi = tail
         assert hi == 0 and sum(b.numel() for _, b in self.buckets) == total
 
     def _bwd_data_conv(self, rec, hwio_index, kind, k, stride, pad, g_src, g_dst):
@@ -317,8 +384,12 @@ class FlowNetSTrainer:
         vy, vg = self._view(dbuf, dc, dc0), self._view(gy, dc, dc0)
         self.keep += [vy, vg]
         db = _hip.ptr(rec["db"]) if rec.get("b") is not None else None
+        # a convolution's bias gradient (the pixel sum of dy) comes out of its filter-gradient launch, which reads dy
+        # anyway; a transposed conv's filter gradient walks x, so its bias (the fusion net's) keeps its own reduction
+        db_fused, db = (db, None) if rec["kind"] != 1 else (None, db)
         if rec["act"]:
-            ops.append((self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg), db)))  # + bias gradient, same pass
+            ops.append((self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg), db)))  # (+ bias gradient, same pass)
+            self._act_ops.append(dict(name=f"{rec['scope']}/{rec['name']}", block=len(self.bwd_ops), vy=vy, vg=vg, db=db))
         elif db is not None:
             ops.append((self.lib.fn2_bias_grad, (C.byref(vg), db)))
         bd = _hip.Fn2BwdwDesc()
@@ -328,6 +399,7 @@ class FlowNetSTrainer:
         bd.kind, bd.kh, bd.kw, bd.stride, bd.pad = rec["kind"], rec["k"], rec["k"], rec["stride"], \
             (0 if rec["kind"] == 2 else rec["pad"])
         bd.cin_pad, bd.cout_pad, bd.kpad, bd.wgt_layout = rec["cin_pad"], rec["cout_pad"], rec["kpad"], rec["layout"]
+        bd.db = db_fused
         self.keep.append(bd)
         ops.append((self.lib.fn2_conv2d_bwd_filter, (C.byref(bd),)))
         if rec["kind"] != 2:  # the stem's input is the image pair: no gradient needed
@@ -382,6 +454,7 @@ class FlowNetSTrainer:
             ga.add_(da)
             gb.add_(db)
             return 0
+        add_grads.writes = [(t.data_ptr(), t.data_ptr() + 4 * t.numel(), 0, t.shape[3]) for t in (ga, gb)]
 
         ops = [(self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg), None)),
                (copy_grad, ()),

@@ -165,6 +165,13 @@ typedef struct {
                           2^k-scaled weights so that split-fp16 lo parts stay normal fp16 numbers */
   void* workspace;     /* fp32 scratch for split-K partial sums, or NULL (then no split-K) */
   int64_t workspace_bytes;
+  /* Backward of LeakyReLU fused into the layer that COMPLETES a gradient slice (training; the reference gets the same
+   * product from tf.gradients of utils.py:401-405): after out (+)= result, channels [act_grad_c0, act_grad_c1) of the
+   * out view are multiplied by 1 / 0.1 / 0.55 for a forward output y > 0 / < 0 / == 0, y read from act_grad_y -- the
+   * forward activation buffer the gradient buffer mirrors: same dtype, geometry and strides as out.data, element for
+   * element.  NULL: off.  fp32 and split-fp16 outputs, act == FN2_ACT_NONE. */
+  const void* act_grad_y;
+  int32_t act_grad_c0, act_grad_c1;
 } fn2_conv_desc;
 
 /* How fn2_conv2d runs a layer of this (input dtype, padded Cin, Cout), i.e. how its weight must be packed:
@@ -304,6 +311,7 @@ typedef struct {
   float* dw;
   int32_t kind, kh, kw, stride, pad;
   int32_t cin_pad, cout_pad, kpad, wgt_layout;
+  float* db;           /* kinds 0 / 2: db[co] += sum over pixels of dy[.., co] in the same pass (the layer's bias gradient), or NULL */
 } fn2_bwdw_desc;
 int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream);
 

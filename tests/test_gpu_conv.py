@@ -35,7 +35,7 @@ def _from_dev(t, code):
 
 
 def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0, cout_off=0, extra_out=0,
-             use_ws=True, force_generic=False, in_f32=False):
+             use_ws=True, force_generic=False, in_f32=False, act_grad=None):
     """Drive the C ABI directly.  x: [N,H,W,Cin] fp32.  Returns fp32 numpy [N,oh,ow,Cout].
     in_f32: fp32 input into a non-fp32 engine format (the stem of a split-fp16 network)."""
     from src import _hip, weights as W
@@ -83,6 +83,12 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
     d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
     d.wgt_layout = plan.layout
     d.out_scale = out_scale
+    if act_grad is not None:  # (y [N,oh,ow,Cout] fp32, c0, c1): out += result, then the LeakyReLU factor from y on [c0, c1)
+        ynp, d.act_grad_c0, d.act_grad_c1 = act_grad
+        ybuf = np.full((N, oh, ow, cs_out), -3.0, np.float32)
+        ybuf[..., cout_off:cout_off + cout] = ynp
+        ydev = _to_dev(ybuf, "f32" if out_code == 0 else dtype)
+        d.act_grad_y, d.accumulate = ydev.data_ptr(), 1
     need = int(lib.fn2_conv2d_workspace_bytes(C.byref(d)))
     ws = None
     if use_ws and need > 0:
@@ -206,6 +212,32 @@ def test_splitk_equals_single_pass(dtype):
     gotd = run_conv(xd, wd, None, "deconv", 4, 2, 1, True, "f32")
     assert run_conv.last_ws_bytes > 0
     np.testing.assert_allclose(gotd, wantd, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+@pytest.mark.parametrize("kind,k,s,p,cin,cout,H,W,c0,c1", [
+    ("conv", 3, 1, 1, 128, 128, 24, 32, 0, 128),     # whole view (the next encoder layer's input gradient); halo kernel
+    ("conv", 3, 1, 1, 256, 194, 12, 16, 64, 128),    # a middle slice of a concat gradient
+    ("conv", 3, 1, 1, 512, 512, 6, 8, 256, 512),     # split-K: the factor is applied by the finalize pass
+    ("deconv", 4, 2, 1, 256, 96, 6, 8, 16, 96),      # four phases
+    ("conv", 5, 1, 2, 64, 48, 16, 24, 16, 48),       # range ending at the view's ragged end
+])
+def test_fused_leaky_backward_in_epilogue(dtype, kind, k, s, p, cin, cout, H, W, c0, c1):
+    """fn2_conv_desc.act_grad_y: out = (out + conv) * LeakyReLU'(y) on channels [c0, c1), untouched elsewhere."""
+    x = rnd((2, H, W, cin), 60)
+    if kind == "conv":
+        w = rnd((k, k, cin, cout), 61, (2.0 / (k * k * cin)) ** 0.5)
+        lin = refnn.conv2d(x, w, None, stride=s, padding=p)
+    else:
+        w = rnd((4, 4, cout, cin), 61, (2.0 / (4 * cin)) ** 0.5)
+        lin = refnn.conv2d_transpose(x, w)
+    y = rnd(lin.shape, 62)
+    y[np.abs(y) < 0.2] = 0.0  # exact zeros take the factor 0.55 (tf.abs' = sign: utils.py:401-405)
+    want = lin + 7.0
+    f = np.where(y > 0, 1.0, np.where(y < 0, 0.1, 0.55)).astype(np.float32)
+    want[..., c0:c1] *= f[..., c0:c1]
+    got = run_conv(x, w, None, kind, k, s, p, False, dtype, cout_off=16, extra_out=16, act_grad=(y, c0, c1))
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
 X2_CASES = [(5, 2, 2, 64, 128, 24, 32), (3, 1, 1, 256, 256, 6, 8), (3, 2, 1, 128, 512, 12, 16),
