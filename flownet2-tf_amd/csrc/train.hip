@@ -361,28 +361,40 @@ __global__ void __launch_bounds__(256) head_bwd_filter_kernel(const T* __restric
     for (int o = 0; o < 2; ++o)
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[t][o][q] = 0.f;
-  if (ci < cin)
-    for (long pix = p0 + pl; pix < p1; pix += 16) {
-      const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
-      float xs[4];
-      load4<T>(x + pix * x_cs + x_c0 + ci, xs);
+  auto one = [&](long pix, const float (&xs)[4]) {
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int oy = iy - ky + 1;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int oy = iy - ky + 1;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ox = ix - kx + 1;
-          float2 gv = make_float2(0.f, 0.f);
-          if (oy >= 0 && oy < H && ox >= 0 && ox < W)
-            gv = *reinterpret_cast<const float2*>(g + (pix + (long)(1 - ky) * W + (1 - kx)) * 2);
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ox = ix - kx + 1;
+        float2 gv = make_float2(0.f, 0.f);
+        if (oy >= 0 && oy < H && ox >= 0 && ox < W)
+          gv = *reinterpret_cast<const float2*>(g + (pix + (long)(1 - ky) * W + (1 - kx)) * 2);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc[ky * 3 + kx][0][q] += xs[q] * gv.x;
-            acc[ky * 3 + kx][1][q] += xs[q] * gv.y;
-          }
+        for (int q = 0; q < 4; ++q) {
+          acc[ky * 3 + kx][0][q] += xs[q] * gv.x;
+          acc[ky * 3 + kx][1][q] += xs[q] * gv.y;
         }
       }
     }
+  };
+  if (ci < cin) {
+    long pix = p0 + pl;
+    for (; pix + 48 < p1; pix += 64) {  // four pixels per trip: their x loads are all in flight before the first FMA
+      float xs[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load4<T>(x + (pix + 16 * u) * x_cs + x_c0 + ci, xs[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(pix + 16 * u, xs[u]);
+    }
+    for (; pix < p1; pix += 16) {
+      float xs[4];
+      load4<T>(x + pix * x_cs + x_c0 + ci, xs);
+      one(pix, xs);
+    }
+  }
   // reduce the 4 pixel lanes of a wave by shuffles, the 4 waves through LDS
   __shared__ float s[4][16][72];
   const int wave = threadIdx.x >> 6;
@@ -1119,7 +1131,8 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   const int it = (a.Ci + 64 * ni - 1) / (64 * ni), jt = (a.Cj + 64 * nj - 1) / (64 * nj);
   // pixel splits: aim at >= ~1024 blocks, ranges multiples of 32 pixels
   long blocks = (long)it * jt * taps;
-  int splits = (int)((1024 + blocks - 1) / blocks);
+  static const int want_blocks = [] { const char* e = getenv("FN2_BWF_BLOCKS"); return e ? atoi(e) : 1024; }();
+  int splits = (int)((want_blocks + blocks - 1) / blocks);
   const int max_splits = (a.P + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

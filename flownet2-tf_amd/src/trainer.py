@@ -247,9 +247,40 @@ class FlowNetSTrainer:
             else:
                 self._plan_conv(rec)
         self._fuse_act_grads()
+        self._plan_zeroing()
         eng._alloc_workspace()  # the input-gradient convolutions share the split-K scratch buffer
         self.refresh_backward_weights()
         self._plan_buckets(4)
+
+    def _writes(self, fn, args):
+        """[(first byte, end byte, c0, c)] of the activation-gradient buffers a backward launch adds into (4-byte
+        elements in every gradient buffer)."""
+        span = lambda v: (v.data, v.data + 4 * v.n * v.h * v.w * v.cs, v.c0, v.c)
+        if fn is self.lib.fn2_conv2d:
+            return [span(args[0]._obj.out)]
+        if fn is self.lib.fn2_head_bwd_data:
+            return [span(args[2]._obj)]
+        return list(getattr(fn, "writes", []))
+
+    def _plan_zeroing(self):
+        """Gradient buffers that need no memset per step: when the FIRST launch that adds into a buffer is an
+        input-gradient convolution over all the channels anyone adds into, that launch stores instead of adding
+        (fn2_conv_desc.accumulate = 0: no zero fill, no read of the old contents).  The pad channels past the real ones
+        are never written and stay zero from the allocation.  FN2_SKIP_ZERO=0: zero everything (A/B)."""
+        self._no_zero = set()  # data pointers of the buffers whose first writer stores
+        if os.environ.get("FN2_SKIP_ZERO", "1") == "0":
+            return
+        for g in self.gbufs.values():
+            g0, g1 = g.data_ptr(), g.data_ptr() + 4 * g.numel()
+            ws = [(fn, args, w) for _name, ops in self.bwd_ops for fn, args in ops for w in self._writes(fn, args)
+                  if w[0] < g1 and g0 < w[1]]
+            if ws and ws[0][0] is self.lib.fn2_conv2d:
+                d = ws[0][1][0]._obj
+                o = d.out
+                top = max(w[2] + w[3] for _fn, _args, w in ws)
+                if d.accumulate and o.data == g0 and (o.n, o.h, o.w, o.cs) == tuple(g.shape) and o.c0 == 0 and o.c >= top:
+                    d.accumulate = 0
+                    self._no_zero.add(g0)
 
     def _fuse_act_grads(self):
         """LeakyReLU backward without its own pass over the tensor: when the last launch that adds into a layer's output
@@ -261,17 +292,7 @@ class FlowNetSTrainer:
         self.fused_act = []
         if os.environ.get("FN2_FUSE_ACT_GRAD", "1") == "0":
             return
-        lib = self.lib
-
-        def writes(fn, args):
-            """[(first byte, end byte, c0, c)] a backward launch adds into (4-byte elements in every gradient buffer)."""
-            span = lambda v: (v.data, v.data + 4 * v.n * v.h * v.w * v.cs, v.c0, v.c)
-            if fn is lib.fn2_conv2d:
-                return [span(args[0]._obj.out)]
-            if fn is lib.fn2_head_bwd_data:
-                return [span(args[2]._obj)]
-            return list(getattr(fn, "writes", []))
-
+        lib, writes = self.lib, self._writes
         for act in self._act_ops:
             bi = act["block"]  # (names repeat: FlowNetC runs conv2 / conv3 once per tower)
             vg, vy = act["vg"], act["vy"]
@@ -544,7 +565,8 @@ class FlowNetSTrainer:
         eng.set_inputs(input_a, input_b)
         self.grad_arena.zero_()
         for g in self.gbufs.values():
-            g.zero_()
+            if g.data_ptr() not in self._no_zero:
+                g.zero_()
         self.loss_dev.zero_()
         eng.launch()
         # ---- loss and its gradient at the five scales (flownet_s.py:122-158)
@@ -721,7 +743,8 @@ class FlowNetSTrainer:
         if seg == 0:
             self.grad_arena.zero_()
             for g in self.gbufs.values():
-                g.zero_()
+                if g.data_ptr() not in self._no_zero:
+                    g.zero_()
             self.loss_dev.zero_()
             eng.launch()
             torch.mul(self.gt, self.gt_scale, out=self._gts)
