@@ -256,7 +256,15 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
     const long pix = i / groups;
     const int co = (int)(i - pix * groups) * 4;
     float4 v = *reinterpret_cast<const float4*>(ws + pix * ws_cs + co);
-    for (int s = 1; s < splitk; ++s) {
+    int s = 1;
+    for (; s + 3 < splitk; s += 4) {  // four slabs in flight; added in split order
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(ws + (s + u) * slab + pix * ws_cs + co);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    }
+    for (; s < splitk; ++s) {
       const float4 t = *reinterpret_cast<const float4*>(ws + s * slab + pix * ws_cs + co);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
@@ -996,6 +1004,7 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   }
   int sk = preferred_split(a, tile, phases);
   while (sk > 1 && (d->workspace == nullptr || split_bytes(a, sk) > d->workspace_bytes)) --sk;
+  if ((long)a.N * a.out_H * a.out_W * a.ws_cs >= (1L << 31)) sk = 1;  // slab offsets are 31-bit (conv2.hip, partial stores)
   if (sk > 1) {
     a.kper = cdiv(a.ksteps, sk);
     sk = cdiv(a.ksteps, a.kper);

@@ -487,8 +487,49 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 
   // ---- epilogue.  Lane (pixel fr of tile tp, half fh) holds couts [16 fh, 16 fh + 16) of cout tile tc.
   OutT* out = reinterpret_cast<OutT*>(p.out);
+  // wave-private LDS tile [pixel][cout] of the epilogues below (the stage buffers are free by now)
+  constexpr int WCOLS = TCN * 32, RS = WCOLS + 4, WROWS = 32 * TPN;   // row stride padded: 16 lanes x float4 hit 16 bank groups
+  constexpr int WREG = WROWS * RS + WROWS;                            // 4-byte words per wave: tile + one offset per row
+  constexpr bool kLdsT = (KG > 1 ? 4 : 2) * WREG * 4 <= KG * ROWS * 128;
+  // K groups: the reduction scratch lives in lds0_all and other waves may still be reading it -> all four in lds1_all
+  float* const tl = reinterpret_cast<float*>(KG > 1 ? lds1_all : (wave < 2 ? lds0_all : lds1_all)) + (KG > 1 ? wave : (wave & 1)) * WREG;
+  constexpr int CPR = WCOLS / 4, RPI = 64 / CPR;   // 16-byte chunks per tile row, rows per wave instruction
   if (p.splitk > 1) {
     float* slab = p.ws + (size_t)split * p.N * p.out_H * p.out_W * p.ws_cs;
+    // The accumulators of a lane are 16 consecutive couts of ONE pixel: stored directly, a wave instruction writes 64
+    // separate 16-byte pieces (one per pixel row of the slab).  Through a wave-private LDS tile [pixel][cout] the same
+    // instruction count writes whole 256-byte runs (16 lanes per pixel row): measured 8-11 % of the kernel on the
+    // split layers (tools/ab_conv.py, FN2_CONV_DBG bit 2097152 of the ablation build).
+    if constexpr (kLdsT) {
+      if constexpr (STAGES == 3) __syncthreads();  // the ring ends without a barrier: other waves may still read their last slot
+      int* rowoff = reinterpret_cast<int*>(tl + WROWS * RS);
+#pragma unroll
+      for (int tp = 0; tp < TPN; ++tp) {
+        const int m = m0 + wp * TPN * 32 + tp * 32 + fr;
+        const int mm = m < p.M ? m : 0;
+        const int n = mm / (p.OH * p.OW);
+        const int rem = mm - n * (p.OH * p.OW);
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        // slab offsets fit 31 bits: the slabs of a launch are < 2 GiB (split_bytes, conv.hip)
+        if (fh == 0) rowoff[tp * 32 + fr] = m < p.M ? (int)((((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.ws_cs) : -1;
+#pragma unroll
+        for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(tl + (tp * 32 + fr) * RS + tc * 32 + fh * 16 + q * 4) =
+                make_float4(acc[tc][tp][4 * q], acc[tc][tp][4 * q + 1], acc[tc][tp][4 * q + 2], acc[tc][tp][4 * q + 3]);
+      }
+      const int rr = lane / CPR, ch = lane - rr * CPR;
+      const int co = c0 + wc * WCOLS + ch * 4;
+#pragma unroll
+      for (int i = 0; i < WROWS / RPI; ++i) {
+        const int row = i * RPI + rr;
+        const float4 v = *reinterpret_cast<const float4*>(tl + row * RS + ch * 4);
+        const int off = rowoff[row];
+        if (off >= 0 && co < p.ws_cs) *reinterpret_cast<float4*>(slab + (size_t)off + co) = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int tp = 0; tp < TPN; ++tp) {
       const int m = m0 + wp * TPN * 32 + tp * 32 + fr;
@@ -510,6 +551,11 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     return;
   }
   const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
+  // 4-byte outputs whose whole wave tile lies inside the view: the finished 16-byte chunks go through the wave's LDS
+  // tile and leave as whole (TCN x 128)-byte runs of a pixel, like the split-K slabs above (wave-uniform choice)
+  const bool wide = kLdsT && sizeof(OutT) == 4 && vec16 && c0 + wc * WCOLS + WCOLS <= p.Cout && !(p.dbg & 4194304);
+  int* const rowoff = reinterpret_cast<int*>(tl + WROWS * RS);
+  if constexpr (STAGES == 3 && kLdsT) __syncthreads();  // (every wave: `wide` may differ between the cout halves of a block)
 #pragma unroll
   for (int tc = 0; tc < TCN; ++tc) {
     const int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
@@ -519,12 +565,13 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 #pragma unroll
     for (int tp = 0; tp < TPN; ++tp) {
       const int m = m0 + wp * TPN * 32 + tp * 32 + fr;
+      if (wide && tc == 0 && fh == 0) rowoff[tp * 32 + fr] = m < p.M ? 0 : -1;
       if (m >= p.M) continue;
       const int n = m / (p.OH * p.OW);
       const int rem = m - n * (p.OH * p.OW);
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      OutT* po = out + (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.out_cs +
-                 p.out_c0 + cout_base;
+      const size_t opix = (((size_t)n * p.out_H + (oy * osc + oy_off)) * p.out_W + (ox * osc + ox_off));
+      OutT* po = out + opix * p.out_cs + p.out_c0 + cout_base;
       float v[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] = acc[tc][tp][q] * p.out_scale + bias[q];
@@ -534,13 +581,27 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = leaky(v[q]);
       }
-      if (vec16 && cout_base + 15 < p.Cout) {
+      if (wide) {
+        if (tc == 0 && fh == 0) rowoff[tp * 32 + fr] = (int)opix;  // pixel index (< 2^31: conv.hip requires M < 2^31 outputs... per view)
+        store16<OutT>(reinterpret_cast<OutT*>(tl + (tp * 32 + fr) * RS + tc * 32 + fh * 16), v);
+      } else if (vec16 && cout_base + 15 < p.Cout) {
         store16<OutT>(po, v);
       } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
           if (cout_base + q < p.Cout) store_elem<OutT>(po + q, v[q]);
       }
+    }
+  }
+  if (wide) {
+    const int rr = lane / CPR, ch = lane - rr * CPR;
+    OutT* ob = out + p.out_c0 + c0 + wc * WCOLS + ch * 4;
+#pragma unroll
+    for (int i = 0; i < WROWS / RPI; ++i) {
+      const int row = i * RPI + rr;
+      const uint4 v = *reinterpret_cast<const uint4*>(tl + row * RS + ch * 4);
+      const int opix = rowoff[row];
+      if (opix >= 0) *reinterpret_cast<uint4*>(ob + (size_t)opix * p.out_cs) = v;
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
