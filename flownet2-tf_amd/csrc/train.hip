@@ -11,6 +11,11 @@ namespace fn2 {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr unsigned kOobT = 0x80000000u;
+// timing ablations of bwd_filter_x2_kernel (FN2_BWF_DBG: 1 no sampled-operand DMA, 2 no dense DMA, 4 no LDS reads / MFMAs,
+// 8 no atomics): compiled in by tools/build_variant.sh abl "-DFN2_BWF_ABLATE=1" only
+#ifndef FN2_BWF_ABLATE
+#define FN2_BWF_ABLATE 0
+#endif
 
 static inline int grid_for(long work_items, int block) {
   long g = (work_items + block - 1) / block;
@@ -474,6 +479,7 @@ __global__ void __launch_bounds__(256) head_bwd_data_kernel(const float* __restr
 // ---------------------------------------------------------------------------
 struct BwdwArgs {
   const float* dn; const float* sm; float* dw;
+  int dbg;                             // FN2_BWF_DBG ablation bits (timing experiments; FN2_CONV_ABLATE builds only)
   float* db;                           // bias gradient db[i] += sum_pix Dn[pix][i] (convolutions: Dn = dY), or nullptr
   int N, DH, DW_, dn_cs, dn_c0, Ci;   // dense tensor: [N, DH, DW] pixels, Ci channels of interest
   int SH, SW, sm_cs, sm_c0, Cj;       // sampled tensor
@@ -528,28 +534,37 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
   const int lgrp = X2 ? (lch & ~7) : lch;
   const bool ch_ok_d = lch < TI && i0 + lgrp < p.Ci, ch_ok_s = lch < TJ && j0 + lgrp < p.Cj;
   // sampled-tensor pixel state of this lane's 4 rows: r = (wave*4 + k)*2 + lrow within the stage
-  int sn[4], sy[4], sx[4];
+  // walking state of the next stage to issue, advanced by additions only (see bwd_filter_x2_kernel)
+  int pixd[4], sy[4], sx[4], iy[4], ix[4], offd[4], offs[4];
+  const int dstep = PK * p.dn_cs * 4, xstep = PK * p.stride * p.sm_cs * 4;
+  const int rowjump = (p.stride * p.SW - p.DW_ * p.stride) * p.sm_cs * 4;
+  const int imgjump = (p.SH - p.DH * p.stride) * p.SW * p.sm_cs * 4;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int pix = pbeg + (wave * 4 + k) * 2 + lrow;
     const int n = pix / (p.DH * p.DW_), rem = pix - n * (p.DH * p.DW_);
-    sn[k] = n; sy[k] = rem / p.DW_; sx[k] = rem - sy[k] * p.DW_;
+    pixd[k] = pix; sy[k] = rem / p.DW_; sx[k] = rem - sy[k] * p.DW_;
+    iy[k] = sy[k] * p.stride + ky - p.pad; ix[k] = sx[k] * p.stride + kx - p.pad;
+    offd[k] = (pix * p.dn_cs + p.dn_c0 + i0 + lch) * 4;
+    offs[k] = (((n * p.SH + iy[k]) * p.SW + ix[k]) * p.sm_cs + p.sm_c0 + j0 + lch) * 4;
   }
   auto issue = [&](int st, float (*lds)[PK * 128]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = (wave * 4 + k) * 2;          // first of the 2 rows of this piece (wave-uniform)
-      const int pix = pbeg + st * PK + r + lrow;  // this lane's pixel
-      const bool pv = pix < pend;
-      const unsigned vd = (pv && ch_ok_d) ? (unsigned)((pix * p.dn_cs + p.dn_c0 + i0 + lch) * 4) : kOobT;
+      const bool pv = pixd[k] < pend;
+      const unsigned vd = (pv && ch_ok_d) ? (unsigned)offd[k] : kOobT;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, vd, 0, 0, 0);
-      const int iy = sy[k] * p.stride + ky - p.pad, ix = sx[k] * p.stride + kx - p.pad;
-      const bool sv = pv && ch_ok_s && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
-      const unsigned vs = sv ? (unsigned)((((sn[k] * p.SH + iy) * p.SW + ix) * p.sm_cs + p.sm_c0 + j0 + lch) * 4) : kOobT;
+      const bool sv = pv && ch_ok_s && (unsigned)iy[k] < (unsigned)p.SH && (unsigned)ix[k] < (unsigned)p.SW;
+      const unsigned vs = sv ? (unsigned)offs[k] : kOobT;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[1][r * 128], 16, vs, 0, 0, 0);
       // advance this row by PK pixels for the next stage
-      sx[k] += PK;
-      while (sx[k] >= p.DW_) { sx[k] -= p.DW_; if (++sy[k] == p.DH) { sy[k] = 0; ++sn[k]; } }
+      pixd[k] += PK; offd[k] += dstep;
+      sx[k] += PK; ix[k] += PK * p.stride; offs[k] += xstep;
+      while (sx[k] >= p.DW_) {
+        sx[k] -= p.DW_; ix[k] -= p.DW_ * p.stride; iy[k] += p.stride; offs[k] += rowjump;
+        if (++sy[k] == p.DH) { sy[k] = 0; iy[k] -= p.DH * p.stride; offs[k] += imgjump; }
+      }
     }
   };
 
@@ -672,7 +687,13 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 // distinct chunk positions mod 16.  5x the matrix rate of the fp32 form (96 vs 512 cycles per 16 pixels of a
 // 32 x 32 tile).
 // ---------------------------------------------------------------------------
-template <bool SWAP, int NI, int NJ>
+// UNI ("uniform walk"): every stage's 32 dense pixels are one piece of an image row (DW % 32 == 0) or whole rows of one
+// image (32 % DW == 0, DH % (32 / DW) == 0) -- all the reference's resolutions.  Then a lane's pixel keeps its place
+// inside the stage: its byte offsets are constants, the stage's position is a handful of scalars (buffer soffset) and
+// the per-stage vector work is one zero-pad test per sampled piece.  The general walk (per-lane pixel state) spent more
+// issue cycles on bookkeeping than on the MFMAs: 56 % of the filter-gradient time ran with neither DMA nor MFMA
+// (FN2_BWF_DBG ablations).
+template <bool SWAP, int NI, int NJ, bool UNI = false>
 __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int PK = 32;
@@ -697,14 +718,71 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
 
   // DMA: lane -> (row lane>>5 of the 2-row piece, physical chunk lane&31); the logical chunk depends on the row
   const int lrow = lane >> 5, lphys = lane & 31;
-  int sn[4], sy[4], sx[4];
+  const int dstep = PK * p.dn_cs * 4, xstep = PK * p.stride * p.sm_cs * 4;
+  const int rowjump = (p.stride * p.SW - p.DW_ * p.stride) * p.sm_cs * 4;  // first pixel of the next dense row
+  const int imgjump = (p.SH - p.DH * p.stride) * p.SW * p.sm_cs * 4;       // ... of the next image
+  // ---- UNI: lane constants + scalar stage position
+  const int sbias = (p.pad * p.SW + p.pad) * p.sm_cs * 4;  // the sampled descriptor starts this far in front of the tensor, so that lane offsets are >= 0
+  const auto rs_su = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.sm)) - sbias, 0, p.sm_bytes + sbias, 0x00020000);
+  unsigned uvd[4], uvs[4];
+  int uiy[4], uix[4];
+  int u_soff_d = 0, u_soff_s = 0, u_yb = 0, u_xb = 0, u_sy = 0, u_sx = 0, u_pix = pbeg;
+  const int rps = p.DW_ >= PK ? 1 : PK / p.DW_;            // image rows per stage
+  const int u_rowstep = rps * p.stride * p.SW * p.sm_cs * 4;
+  if constexpr (UNI) {
+    const int n0 = pbeg / (p.DH * p.DW_), rem0 = pbeg - n0 * (p.DH * p.DW_);
+    u_yb = rem0 / p.DW_; u_xb = rem0 - u_yb * p.DW_;
+    u_sy = u_yb * p.stride; u_sx = u_xb * p.stride;
+    u_soff_d = pbeg * p.dn_cs * 4;
+    u_soff_s = ((n0 * p.SH + u_sy) * p.SW + u_sx) * p.sm_cs * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = (wave * 4 + k) * 2 + lrow;
+      const int dy = p.DW_ >= PK ? 0 : r / p.DW_, dx = p.DW_ >= PK ? r : r - dy * p.DW_;
+      uiy[k] = dy * p.stride + ky - p.pad; uix[k] = dx * p.stride + kx - p.pad;
+      const int L = lphys ^ ((r & 1) | ((r & 2) << 2));
+      const int grp_ch = (L >> 1) * 8;
+      uvd[k] = (grp_ch < TI && i0 + grp_ch < p.Ci) ? (unsigned)((r * p.dn_cs + p.dn_c0 + i0) * 4 + L * 16) : kOobT;
+      uvs[k] = (grp_ch < TJ && j0 + grp_ch < p.Cj)
+                   ? (unsigned)(((uiy[k] * p.SW + uix[k]) * p.sm_cs + p.sm_c0 + j0) * 4 + L * 16 + sbias) : kOobT;
+    }
+  }
+  auto issue_uni = [&](float (*lds)[PK * 128]) {
+    const bool ok = u_pix < pend;   // uniform: ranges and the tensor are whole stages
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = (wave * 4 + k) * 2;
+      if (!(FN2_BWF_ABLATE && (p.dbg & 2)))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, ok ? uvd[k] : kOobT, u_soff_d, 0, 0);
+      const bool sv = ok && (unsigned)(u_sy + uiy[k]) < (unsigned)p.SH && (unsigned)(u_sx + uix[k]) < (unsigned)p.SW;
+      if (!(FN2_BWF_ABLATE && (p.dbg & 1)))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_su, (lptr_t)&lds[1][r * 128], 16, sv ? uvs[k] : kOobT, u_soff_s, 0, 0);
+    }
+    u_pix += PK; u_soff_d += dstep;
+    if (p.DW_ >= PK) {
+      u_xb += PK; u_sx += PK * p.stride; u_soff_s += xstep;
+      if (u_xb == p.DW_) {
+        u_xb = 0; u_sx = 0; u_soff_s += rowjump; u_sy += p.stride;
+        if (++u_yb == p.DH) { u_yb = 0; u_sy = 0; u_soff_s += imgjump; }
+      }
+    } else {
+      u_yb += rps; u_sy += rps * p.stride; u_soff_s += u_rowstep;
+      if (u_yb == p.DH) { u_yb = 0; u_sy = 0; u_soff_s += imgjump; }
+    }
+  };
+  // ---- general walk.  Per-row state: every quantity of the NEXT stage to issue is kept up to date by additions (the products
+  // pixel * stride, row * width ... of the first version were 32 quarter-rate integer multiplies per two stages and wave)
+  int pixd[4], sy[4], sx[4], iy[4], ix[4], offd[4], offs[4];
   unsigned coff_d[4], coff_s[4];  // byte offset of this lane's logical chunk inside the tile's 512-byte row, or OOB
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = (wave * 4 + k) * 2 + lrow;
     const int pix = pbeg + r;
     const int n = pix / (p.DH * p.DW_), rem = pix - n * (p.DH * p.DW_);
-    sn[k] = n; sy[k] = rem / p.DW_; sx[k] = rem - sy[k] * p.DW_;
+    pixd[k] = pix; sy[k] = rem / p.DW_; sx[k] = rem - sy[k] * p.DW_;
+    iy[k] = sy[k] * p.stride + ky - p.pad; ix[k] = sx[k] * p.stride + kx - p.pad;
+    offd[k] = (pix * p.dn_cs + p.dn_c0 + i0) * 4;
+    offs[k] = (((n * p.SH + iy[k]) * p.SW + ix[k]) * p.sm_cs + p.sm_c0 + j0) * 4;
     const int L = lphys ^ ((r & 1) | ((r & 2) << 2));
     const int grp_ch = (L >> 1) * 8;  // first channel of the group this chunk belongs to
     coff_d[k] = (grp_ch < TI && i0 + grp_ch < p.Ci) ? (unsigned)(L * 16) : kOobT;
@@ -714,16 +792,18 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = (wave * 4 + k) * 2;
-      const int pix = pbeg + st * PK + r + lrow;
-      const bool pv = pix < pend;
-      const unsigned vd = (pv && coff_d[k] != kOobT) ? (unsigned)((pix * p.dn_cs + p.dn_c0 + i0) * 4) + coff_d[k] : kOobT;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, vd, 0, 0, 0);
-      const int iy = sy[k] * p.stride + ky - p.pad, ix = sx[k] * p.stride + kx - p.pad;
-      const bool sv = pv && coff_s[k] != kOobT && iy >= 0 && iy < p.SH && ix >= 0 && ix < p.SW;
-      const unsigned vs = sv ? (unsigned)((((sn[k] * p.SH + iy) * p.SW + ix) * p.sm_cs + p.sm_c0 + j0) * 4) + coff_s[k] : kOobT;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[1][r * 128], 16, vs, 0, 0, 0);
-      sx[k] += PK;
-      while (sx[k] >= p.DW_) { sx[k] -= p.DW_; if (++sy[k] == p.DH) { sy[k] = 0; ++sn[k]; } }
+      const bool pv = pixd[k] < pend;
+      const unsigned vd = (pv && coff_d[k] != kOobT) ? (unsigned)offd[k] + coff_d[k] : kOobT;
+      if (!(FN2_BWF_ABLATE && (p.dbg & 2))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, vd, 0, 0, 0);
+      const bool sv = pv && coff_s[k] != kOobT && (unsigned)iy[k] < (unsigned)p.SH && (unsigned)ix[k] < (unsigned)p.SW;
+      const unsigned vs = sv ? (unsigned)offs[k] + coff_s[k] : kOobT;
+      if (!(FN2_BWF_ABLATE && (p.dbg & 1))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[1][r * 128], 16, vs, 0, 0, 0);
+      pixd[k] += PK; offd[k] += dstep;
+      sx[k] += PK; ix[k] += PK * p.stride; offs[k] += xstep;
+      while (sx[k] >= p.DW_) {
+        sx[k] -= p.DW_; ix[k] -= p.DW_ * p.stride; iy[k] += p.stride; offs[k] += rowjump;
+        if (++sy[k] == p.DH) { sy[k] = 0; iy[k] -= p.DH * p.stride; offs[k] += imgjump; }
+      }
     }
   };
 
@@ -757,6 +837,7 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
     return o;
   };
   auto compute = [&](const float (*lds)[PK * 128]) {
+    if (FN2_BWF_ABLATE && (p.dbg & 4)) return;
 #pragma unroll
     for (int pb = 0; pb < PK; pb += 16) {
       uint4 ah[NI], al[NI], bh[NJ], bl[NJ];
@@ -796,17 +877,21 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
               (float)*reinterpret_cast<const _Float16*>(base + row * 512 + ((L + 1) ^ sw) * 16);
     }
   };
-  issue(0, lds0);
+  auto issue_any = [&](int st, float (*lds)[PK * 128]) {
+    if constexpr (UNI) issue_uni(lds);
+    else issue(st, lds);
+  };
+  issue_any(0, lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int nstage2 = (nstage + 1) & ~1;
   for (int st = 0; st < nstage2; st += 2) {
-    issue(st + 1, lds1);
+    issue_any(st + 1, lds1);
     compute(lds0);
     bias_stage(lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (st + 2 < nstage2) issue(st + 2, lds0);
+    if (st + 2 < nstage2) issue_any(st + 2, lds0);
     compute(lds1);
     bias_stage(lds1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -819,6 +904,7 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
   }
   const int fr = lane & 31, fk = lane >> 5;
   float* base = p.dw + p.tap_base[tap];
+  if (FN2_BWF_ABLATE && (p.dbg & 8)) return;
 #pragma unroll
   for (int ti = 0; ti < NI; ++ti)
 #pragma unroll
@@ -1120,6 +1206,7 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   a.dn = (const float*)dn->data; a.sm = (const float*)sm->data; a.dw = d->dw;
   FN2_REQUIRE(d->db == nullptr || d->kind != 1, "bwd_filter: the fused bias gradient sums dy, the dense operand of convolutions only");
   a.db = d->db;
+  { const char* e = getenv("FN2_BWF_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.N = dn->n; a.DH = dn->h; a.DW_ = dn->w; a.dn_cs = dn->cs; a.dn_c0 = dn->c0; a.Ci = dn->c;
   a.SH = sm->h; a.SW = sm->w; a.sm_cs = sm->cs; a.sm_c0 = sm->c0; a.Cj = d->kind == 2 ? d->kw * sm->cs : sm->c;
   const long dnb = (long)dn->n * dn->h * dn->w * dn->cs * 4, smb = (long)sm->n * sm->h * sm->w * sm->cs * 4;
@@ -1129,9 +1216,11 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   const int taps = a.KH * a.KW;
   const int ni = a.Ci <= 64 ? 1 : 2, nj = a.Cj <= 64 ? 1 : 2;
   const int it = (a.Ci + 64 * ni - 1) / (64 * ni), jt = (a.Cj + 64 * nj - 1) / (64 * nj);
-  // pixel splits: aim at >= ~1024 blocks, ranges multiples of 32 pixels
+  // pixel splits: aim at >= ~384 blocks, ranges multiples of 32 pixels
   long blocks = (long)it * jt * taps;
-  static const int want_blocks = [] { const char* e = getenv("FN2_BWF_BLOCKS"); return e ? atoi(e) : 1024; }();
+  // (measured on the FlowNetS step: 1024 -> 5.79 ms, 512 -> 5.77, 384 -> 5.64, 256 -> 5.75, 192 -> 6.0: a quarter of the
+  // kernel's time is its fp32 atomics, whose count grows with the pixel splits)
+  static const int want_blocks = [] { const char* e = getenv("FN2_BWF_BLOCKS"); return e ? atoi(e) : 384; }();
   int splits = (int)((want_blocks + blocks - 1) / blocks);
   const int max_splits = (a.P + 255) / 256;
   if (splits > max_splits) splits = max_splits;
@@ -1142,11 +1231,16 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 #define FN2_BWF(SW_, NI_, NJ_)                                                                       \
   do {                                                                                               \
-    if (x2 && x2_mfma) hipLaunchKernelGGL((bwd_filter_x2_kernel<SW_, NI_, NJ_>), grid, block, 0, st, a); \
+    if (x2 && x2_mfma && uni) hipLaunchKernelGGL((bwd_filter_x2_kernel<SW_, NI_, NJ_, true>), grid, block, 0, st, a); \
+    else if (x2 && x2_mfma) hipLaunchKernelGGL((bwd_filter_x2_kernel<SW_, NI_, NJ_, false>), grid, block, 0, st, a); \
     else if (x2) hipLaunchKernelGGL((bwd_filter_kernel<SW_, NI_, NJ_, true>), grid, block, 0, st, a);  \
     else hipLaunchKernelGGL((bwd_filter_kernel<SW_, NI_, NJ_, false>), grid, block, 0, st, a);        \
   } while (0)
   const bool x2 = d->x.dtype == FN2_F16X2;
+  // uniform walk (bwd_filter_x2_kernel<.., UNI>): a stage = 32 pixels of one image row, or whole rows of one image.
+  // FN2_BWF_UNI=0: the general per-lane walk everywhere (A/B)
+  static const bool uni_on = [] { const char* e = getenv("FN2_BWF_UNI"); return !e || atoi(e) != 0; }();
+  const bool uni = uni_on && (a.DW_ % 32 == 0 || (32 % a.DW_ == 0 && a.DH % (32 / a.DW_) == 0));
   const char* dbg_env = getenv("FN2_CONV_DBG");
   const bool x2_mfma = !(dbg_env && (atoi(dbg_env) & 128));  // bit 128: the fp32-MFMA form on split-fp16 tensors (A/B)
   if (d->kind == 1) {
