@@ -366,38 +366,30 @@ __global__ void __launch_bounds__(256) head_bwd_filter_kernel(const T* __restric
     for (int o = 0; o < 2; ++o)
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[t][o][q] = 0.f;
-  auto one = [&](long pix, const float (&xs)[4]) {
-    const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int oy = iy - ky + 1;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ox = ix - kx + 1;
-        float2 gv = make_float2(0.f, 0.f);
-        if (oy >= 0 && oy < H && ox >= 0 && ox < W)
-          gv = *reinterpret_cast<const float2*>(g + (pix + (long)(1 - ky) * W + (1 - kx)) * 2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[ky * 3 + kx][0][q] += xs[q] * gv.x;
-          acc[ky * 3 + kx][1][q] += xs[q] * gv.y;
-        }
-      }
-    }
-  };
   if (ci < cin) {
-    long pix = p0 + pl;
-    for (; pix + 48 < p1; pix += 64) {  // four pixels per trip: their x loads are all in flight before the first FMA
-      float xs[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) load4<T>(x + (pix + 16 * u) * x_cs + x_c0 + ci, xs[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) one(pix + 16 * u, xs[u]);
-    }
-    for (; pix < p1; pix += 16) {
+    // (more loads in flight were tried both ways: four pixels per trip with their loads up front took 256 VGPRs, one wave
+    // per SIMD and twice the time; the next pixel's x loaded before this pixel's FMAs was 10-30 % slower, capping the
+    // kernel at 128 VGPRs for a fourth wave per SIMD spilled and was 25 % slower)
+    for (long pix = p0 + pl; pix < p1; pix += 16) {
+      const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
       float xs[4];
       load4<T>(x + pix * x_cs + x_c0 + ci, xs);
-      one(pix, xs);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int oy = iy - ky + 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ox = ix - kx + 1;
+          float2 gv = make_float2(0.f, 0.f);
+          if (oy >= 0 && oy < H && ox >= 0 && ox < W)
+            gv = *reinterpret_cast<const float2*>(g + (pix + (long)(1 - ky) * W + (1 - kx)) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[ky * 3 + kx][0][q] += xs[q] * gv.x;
+            acc[ky * 3 + kx][1][q] += xs[q] * gv.y;
+          }
+        }
+      }
     }
   }
   // reduce the 4 pixel lanes of a wave by shuffles, the 4 waves through LDS
