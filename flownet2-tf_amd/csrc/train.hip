@@ -345,6 +345,35 @@ __global__ void __launch_bounds__(256) upsample_flow_bwd_kernel(const T* __restr
   if (threadIdx.x < 64) atomicAdd(dw + threadIdx.x, sdw[threadIdx.x]);
 }
 
+// The gradient of a flow head's output (3x3, stride 1, pad 1, Cout = 2) as an 18-"channel" tensor:
+//   G18[pix][tap * 2 + o] = g[pix + (1 - ky) W + (1 - kx)][o]   (tap = ky * 3 + kx; 0 where that pixel is outside)
+// With it both gradients of the head are ordinary matrix products on the kernels the other layers use:
+//   dW[o][tap][ci] = sum_pix G18[pix][tap, o] x[pix][ci]   -> bwd_filter (kind 4: 1x1, rows mapped into the head's layout)
+//   dx[pix][ci]   += sum_c18 G18[pix][c18] W[c18][ci]      -> fn2_conv2d, 1x1, accumulate
+// Split fp16, channel stride >= 24: a thread writes one 8-channel group (4 taps) of a pixel; groups past channel 23
+// are never written (they stay the zeros of the allocation, their weights are zero rows).
+__global__ void __launch_bounds__(256) head_g18_kernel(const float* __restrict__ g, x2_t* __restrict__ out, int out_cs,
+                                                       int out_c0, int N, int H, int W) {
+  const long total = (long)N * H * W * 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / 3;
+    const int grp = (int)(i - pix * 3);
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tap = grp * 4 + t, ky = tap / 3, kx = tap - ky * 3;
+      const int oy = y + 1 - ky, ox = x + 1 - kx;
+      float2 gv = make_float2(0.f, 0.f);
+      if (tap < 9 && oy >= 0 && oy < H && ox >= 0 && ox < W)
+        gv = *reinterpret_cast<const float2*>(g + (pix + (long)(1 - ky) * W + (1 - kx)) * 2);
+      v[2 * t] = gv.x; v[2 * t + 1] = gv.y;
+    }
+    uint4* q = reinterpret_cast<uint4*>(out + pix * out_cs + out_c0 + grp * 8);
+    split8(v, q[0], q[1]);
+  }
+}
+
 // Flow-head filter gradient (3x3, stride 1, pad 1, Cout = 2):
 //   dw[co][tap*cin_pad + ci] += sum_{iy,ix} x[iy][ix][ci] * g[iy - ky + 1][ix - kx + 1][co]
 // x is read ONCE: a thread owns 4 channels (one float4 per pixel) and all 9 taps x 2 outputs = 72 accumulators;
@@ -471,6 +500,7 @@ __global__ void __launch_bounds__(256) head_bwd_data_kernel(const float* __restr
 // ---------------------------------------------------------------------------
 struct BwdwArgs {
   const float* dn; const float* sm; float* dw;
+  int head_kpad, head_cin_pad;         // kind 4 (flow head from G18): row i = (tap, o) goes to (i & 1) * kpad + (i >> 1) * cin_pad; else 0
   int dbg;                             // FN2_BWF_DBG ablation bits (timing experiments; FN2_CONV_ABLATE builds only)
   float* db;                           // bias gradient db[i] += sum_pix Dn[pix][i] (convolutions: Dn = dY), or nullptr
   int N, DH, DW_, dn_cs, dn_c0, Ci;   // dense tensor: [N, DH, DW] pixels, Ci channels of interest
@@ -661,7 +691,8 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int i = i0 + wi * NI * 32 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
-          if (i < p.Ci) atomicAdd(base + (long)(p.perm_i ? perm32(i) : i) * p.stride_i + oj, acc[ti][tj][q]);
+          if (i < p.Ci) atomicAdd(base + (p.head_kpad ? (long)(i & 1) * p.head_kpad + (long)(i >> 1) * p.head_cin_pad
+                                                   : (long)(p.perm_i ? perm32(i) : i) * p.stride_i) + oj, acc[ti][tj][q]);
         }
       }
     }
@@ -917,7 +948,8 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int i = i0 + wi * NI * 32 + ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
-          if (i < p.Ci) atomicAdd(base + (long)(p.perm_i ? perm32(i) : i) * p.stride_i + oj, acc[ti][tj][q]);
+          if (i < p.Ci) atomicAdd(base + (p.head_kpad ? (long)(i & 1) * p.head_kpad + (long)(i >> 1) * p.head_cin_pad
+                                                   : (long)(p.perm_i ? perm32(i) : i) * p.stride_i) + oj, acc[ti][tj][q]);
         }
       }
     }
@@ -1114,6 +1146,17 @@ int fn2_upsample_flow_bwd(const fn2_tensor* g, const float* pf, const float* w, 
   return FN2_OK;
 }
 
+int fn2_head_g18(const float* g, const fn2_tensor* out, void* stream) {
+  FN2_REQUIRE(g && out && out->data, "head_g18: null pointer");
+  FN2_REQUIRE(out->dtype == FN2_F16X2 && out->c == 18 && out->cs % 8 == 0 && out->c0 % 8 == 0 && out->cs - out->c0 >= 24,
+              "head_g18: the output is an 18-channel split-fp16 view with room for three 8-channel groups");
+  const long total = (long)out->n * out->h * out->w * 3;
+  hipLaunchKernelGGL(head_g18_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, g, (x2_t*)out->data,
+                     out->cs, out->c0, out->n, out->h, out->w);
+  FN2_CHECK_LAUNCH("head_g18");
+  return FN2_OK;
+}
+
 int fn2_head_bwd_filter(const fn2_tensor* x, const float* g, float* dw, int cin_pad, int kpad, void* stream) {
   FN2_REQUIRE(x && x->data && g && dw, "head_bwd_filter: null pointer");
   FN2_REQUIRE((x->dtype == FN2_F32 || x->dtype == FN2_F16X2) && cin_pad >= x->c && kpad >= 9 * cin_pad, "head_bwd_filter: bad layout");
@@ -1159,15 +1202,27 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
               "bwd_filter: x and dy must both be fp32 or both split fp16");
   if (d->x.dtype == FN2_F16X2)
     FN2_REQUIRE(d->x.cs % 8 == 0 && d->x.c0 % 8 == 0 && d->dy.cs % 8 == 0 && d->dy.c0 % 8 == 0, "bwd_filter: split-fp16 views are group (8) aligned");
-  FN2_REQUIRE(d->kind >= 0 && d->kind <= 2, "bwd_filter: kind 0 (conv), 1 (deconv k4 s2 crop 1) or 2 (stem row-run conv)");
+  FN2_REQUIRE((d->kind >= 0 && d->kind <= 2) || d->kind == 4,
+              "bwd_filter: kind 0 (conv), 1 (deconv k4 s2 crop 1), 2 (stem row-run conv) or 4 (flow head from fn2_head_g18)");
   FN2_REQUIRE(d->x.n == d->dy.n, "bwd_filter: batch mismatch");
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cout_pad >= d->dy.c && d->kpad > 0, "bwd_filter: bad packed sizes");
   FN2_REQUIRE((d->x.cs % 4) == 0 && (d->x.c0 % 4) == 0 && (d->dy.cs % 4) == 0 && (d->dy.c0 % 4) == 0,
               "bwd_filter: views must be 16-byte aligned");
   BwdwArgs a;
+  a.head_kpad = a.head_cin_pad = 0;
   const fn2_tensor* dn;
   const fn2_tensor* sm;
-  if (d->kind == 0 || d->kind == 2) {
+  if (d->kind == 4) {
+    // flow head: dy = G18 (fn2_head_g18: 18 channels = 9 taps x 2 outputs, already shifted), a 1x1 product with x; the
+    // rows land in the head's natural layout dw[o][tap * cin_pad + ci]
+    FN2_REQUIRE(d->dy.c == 18 && d->dy.h == d->x.h && d->dy.w == d->x.w && d->kpad >= 9 * d->cin_pad && d->wgt_layout == 0 && d->db == nullptr,
+                "bwd_filter: kind 4 takes the 18-channel tensor of fn2_head_g18 and the head's natural weight layout");
+    dn = &d->dy; sm = &d->x;
+    a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
+    a.stride_i = 0; a.stride_j = 1; a.perm_i = 0; a.perm_j = 0;
+    a.tap_base[0] = 0;
+    a.head_kpad = d->kpad; a.head_cin_pad = d->cin_pad;
+  } else if (d->kind == 0 || d->kind == 2) {
     FN2_REQUIRE(d->kh >= 1 && d->kh * d->kw <= 49 && d->stride >= 1 && d->pad >= 0, "bwd_filter: bad geometry");
     if (d->kind == 2) FN2_REQUIRE(d->pad == 0 && d->x.c0 == 0 && d->cin_pad >= d->kw * d->x.cs, "bwd_filter: stem layout");
     FN2_REQUIRE(d->dy.h == (d->x.h + 2 * d->pad - d->kh) / d->stride + 1 && d->dy.w == (d->x.w + 2 * d->pad - d->kw) / d->stride + 1,
@@ -1235,7 +1290,7 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   const bool uni = uni_on && (a.DW_ % 32 == 0 || (32 % a.DW_ == 0 && a.DH % (32 / a.DW_) == 0));
   const char* dbg_env = getenv("FN2_CONV_DBG");
   const bool x2_mfma = !(dbg_env && (atoi(dbg_env) & 128));  // bit 128: the fp32-MFMA form on split-fp16 tensors (A/B)
-  if (d->kind == 1) {
+  if (d->kind == 1) {  // (kinds 0, 2, 4 below)
     if (ni == 2 && nj == 2) FN2_BWF(true, 2, 2); else if (ni == 2) FN2_BWF(true, 2, 1);
     else if (nj == 2) FN2_BWF(true, 1, 2); else FN2_BWF(true, 1, 1);
   } else {

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "fn2_adam_step_multi_dev": (_i, [_p, _p, _p, _i, _p, _p]),
     "fn2_upsample_flow_bwd": (_i, [_tp, _p, _p, _p, _p, _i, _p]),
     "fn2_head_bwd_filter": (_i, [_tp, _p, _p, _i, _i, _p]),
+    "fn2_head_g18": (_i, [_p, _tp, _p]),
     "fn2_head_bwd_data": (_i, [_p, _p, _tp, _i, _i, _p]),
     "fn2_conv2d_bwd_filter": (_i, [C.POINTER(Fn2BwdwDesc), _p]),
     "fn2_capture_begin": (_i, [_p]),

@@ -445,6 +445,33 @@ class FlowNetSTrainer:
         gx = self._gbuf(sbuf)
         vx, vg = self._view(sbuf, sc, sc0), self._view(dpf, 2, 0)
         self.keep += [vx, vg]
+        if self.x2 and os.environ.get("FN2_HEAD_MFMA", "1") != "0":
+            # split-fp16 trainer: the head's output gradient as the 18-channel tensor G18 (fn2_head_g18), then both
+            # gradients are matrix products on the kernels of the other layers -- the filter gradient a 1x1 launch of
+            # the filter-gradient kernel (kind 4), the input gradient a 1x1 accumulating convolution from G18
+            n, h, w = int(pf.shape[0]), int(pf.shape[1]), int(pf.shape[2])
+            g18 = torch.zeros((n, h, w, 32), dtype=torch.float32, device=self.dev)  # split fp16 in an fp32 container
+            self.gcode[g18.data_ptr()] = _hip.FN2_F16X2
+            v18 = self._view(g18, 18, 0)
+            self.keep += [g18, v18]
+            ops = [(self.lib.fn2_head_g18, (_hip.ptr(dpf), C.byref(v18)))]
+            bd = _hip.Fn2BwdwDesc()
+            bd.x, bd.dy, bd.dw = vx, v18, rec["dw"].data_ptr()
+            bd.kind, bd.kh, bd.kw, bd.stride, bd.pad = 4, 3, 3, 1, 1
+            bd.cin_pad, bd.cout_pad, bd.kpad, bd.wgt_layout = rec["cin_pad"], 32, rec["kpad"], 0
+            self.keep.append(bd)
+            ops.append((self.lib.fn2_conv2d_bwd_filter, (C.byref(bd),)))
+            if rec.get("b") is not None:
+                ops.append((self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"]))))
+            # W18[c18 = tap * 2 + o][ci] = w[o][tap * cin_pad + ci] of the natural-order master, as a 1x1 HWIO index
+            idx = np.zeros((1, 1, 18, sc), np.int64)
+            for tap in range(9):
+                for o in range(2):
+                    idx[0, 0, tap * 2 + o, :] = o * rec["kpad"] + tap * rec["cin_pad"] + np.arange(sc)
+            d = self._bwd_data_conv(rec, idx, 0, 1, 1, 0, (g18, 0, 18), (gx, sc0, sc))
+            ops.append((self.lib.fn2_conv2d, (C.byref(d),)))
+            self.bwd_ops.append((f"{rec['scope']}/{rec['name']}", ops))
+            return
         ops = [(self.lib.fn2_head_bwd_filter, (C.byref(vx), _hip.ptr(dpf), _hip.ptr(rec["dw"]), rec["cin_pad"], rec["kpad"]))]
         if rec.get("b") is not None:  # FlowNetS_interp's heads carry no biases (no_deconv_biases, flownet_s_interp.py:86-95)
             ops.append((self.lib.fn2_bias_grad, (C.byref(vg), _hip.ptr(rec["db"]))))

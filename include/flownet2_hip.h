@@ -314,6 +314,13 @@ typedef struct {
   float* db;           /* kinds 0 / 2: db[co] += sum over pixels of dy[.., co] in the same pass (the layer's bias gradient), or NULL */
 } fn2_bwdw_desc;
 int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream);
+/* Flow heads (predict_flowN: 3x3, pad 1, 2 outputs) through the matrix-core kernels: fn2_head_g18 writes the head's
+ * output gradient g [n, h, w, 2] (fp32) as the 18-channel split-fp16 tensor G18[pix][tap * 2 + o] = g[pix shifted by the
+ * tap][o] (zero outside the image) into `out` (c == 18, at least 24 channels of room; channels >= 24 of a wider buffer
+ * must be zero and stay untouched).  Then fn2_conv2d_bwd_filter with kind 4 (x = head input, dy = G18, dw = the head's
+ * natural-order weight gradient [2][kpad], cin_pad, kpad of the head) is the filter gradient, and a 1x1 fn2_conv2d from
+ * G18 with accumulate the input gradient.  (fn2_head_bwd_filter / fn2_head_bwd_data are the fp32-tensor forms.) */
+int fn2_head_g18(const float* g, const fn2_tensor* out, void* stream);
 
 /* ---------------------------------------------------------------- training-input augmentation
  * The reference's preprocessing plugin (src/ops/preprocessing/preprocessing.cc:24-95).  The random coefficients
