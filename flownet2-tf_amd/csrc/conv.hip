@@ -789,6 +789,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   a.N = d->in.n; a.H = d->in.h; a.W = d->in.w; a.in_cs = d->in.cs; a.in_c0 = d->in.c0;
   a.cin_chunks = d->cin_pad / CH;
   int phases = 1;
+  int trim[2] = {0, 0};  // kind 3: taps per phase parity (0 = all KH x KW)
   if (d->kind == 0) {
     FN2_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->pad >= 0, "conv2d: bad kernel geometry");
     a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad;
@@ -838,7 +839,16 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     a.ph_pad0 = -ceil_half(0 + d->pad - d->kh + 1);
     a.ph_pad1 = -ceil_half(1 + d->pad - d->kh + 1);
     phases = 4;
+    // phase a holds ky = ky0, ky0 - 2, ... >= 0 with ky0 = a + p + 2 ph_pad_a: a prefix of its T tap slots
+    const char* e_trim = getenv("FN2_TRIM_TAPS");  // 0: walk the zero slots as well (A/B)
+    if (!e_trim || atoi(e_trim) != 0)
+      for (int ph = 0; ph < 2; ++ph) {
+        const int ky0 = ph + d->pad + 2 * (ph ? a.ph_pad1 : a.ph_pad0);
+        const int t = ky0 < 0 ? 0 : ky0 / 2 + 1;
+        trim[ph] = t < T ? t : T;
+      }
   }
+  for (int ph = 0; ph < 2; ++ph) { a.kh_ph[ph] = trim[ph] > 0 ? trim[ph] : a.KH; a.kw_ph[ph] = trim[ph] > 0 ? trim[ph] : a.KW; }
   a.accum = d->accumulate ? 1 : 0;
   a.mask_y = d->act_grad_y; a.mask_c0 = d->act_grad_c0; a.mask_c1 = d->act_grad_c1;
   if (a.mask_y != nullptr) {

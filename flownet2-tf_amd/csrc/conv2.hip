@@ -123,8 +123,11 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     pad_y = a ? p.ph_pad1 : p.ph_pad0; pad_x = b ? p.ph_pad1 : p.ph_pad0; oy_off = a; ox_off = b; osc = 2;
     wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
   }
+  // taps this block walks: the phases of a transposed stride-2 conv have fewer than KH x KW (zero slots are skipped)
+  const int khi = p.deconv ? p.kh_ph[phase >> 1] : p.KH, kwi = p.deconv ? p.kw_ph[phase & 1] : p.KW;
+  const int nst_all = (p.cin_chunks >> 3) * khi * kwi;
   const int kt0 = split * p.kper + grp;  // first stage of this K group
-  const int kt1 = (FN2_CONV_ABLATE && (p.dbg & 1048576)) ? kt0 : min(p.ksteps, split * p.kper + p.kper);  // ablation: no K loop
+  const int kt1 = (FN2_CONV_ABLATE && (p.dbg & 1048576)) ? kt0 : min(nst_all, split * p.kper + p.kper);  // ablation: no K loop
   // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id
   // order, so with the plain mapping a pixel tile's vertical neighbours and its other cout tiles run on other
   // XCDs / much later: every 3x3 halo row and every extra cout tile re-read the activations from HBM.  Give
@@ -190,11 +193,11 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   // distance was a whole pass over the channels and every tap missed L2: FETCH_SIZE showed the 3x3 layers
   // fetching their input 6-9 times (conv3_1: 449 MB for a 47 MB input).  Only the summation order changes.
   const int spt = p.cin_chunks >> 3;  // 128-byte stages per tap
-  const int ntap = p.KH * p.KW;
+  const int ntap = khi * kwi;
   const bool tap_outer = FN2_CONV_ABLATE && (p.dbg & 16);  // A/B switch: the first version's order
   int sc = tap_outer ? kt0 % spt : kt0 / ntap;  // channel block of stage kt0
   int tap = tap_outer ? kt0 / spt : kt0 - sc * ntap;
-  int ky = tap / p.KW, kx = tap - ky * p.KW;
+  int ky = tap / kwi, kx = tap - ky * kwi;
   int wstage = kt0;  // position in this order; the weight row offset of the stage is ((ky*KW + kx)*spt + sc) * 128
 
   auto issue_piece = [&](auto piece_c, uint4* lds) {
@@ -216,12 +219,12 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     if (tap_outer) {
       if (++sc == spt) {
         sc = 0;
-        if (++kx == p.KW) { kx = 0; ++ky; }
+        if (++kx == kwi) { kx = 0; ++ky; }
       }
-      if (ky == p.KH) { ky = 0; sc = spt; }  // past the end: park on an always-masked state
-    } else if (++kx == p.KW) {
+      if (ky == khi) { ky = 0; sc = spt; }  // past the end: park on an always-masked state
+    } else if (++kx == kwi) {
       kx = 0;
-      if (++ky == p.KH) { ky = 0; ++sc; }
+      if (++ky == khi) { ky = 0; ++sc; }
     }
   };
   auto advance = [&]() {
@@ -1119,6 +1122,7 @@ static bool launch_stem(const ConvArgs& a, int tile, int phases, hipStream_t s) 
 template <typename OutT>
 static bool launch_halo(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   if ((a.dbg & 2048) || a.stride != 1 || a.splitk != 1 || a.kg != 1 || !a.bp64 || (a.KW != 2 && a.KW != 3)) return false;
+  if (a.deconv && (a.kh_ph[0] != a.KH || a.kh_ph[1] != a.KH || a.kw_ph[0] != a.KW || a.kw_ph[1] != a.KW)) return false;  // trimmed phases: conv_igemm2_kernel
   // one-round 128 x 64 grids (384..512 blocks) keep the 3-slot ring: two stages of DMA in flight beat the smaller
   // stream there (conv3_1 at batch 4: ring 0.196 ms per 3 launches, halo 0.213)
   if (tile == 128 && a.bp64 == 2 && !(a.dbg & 4096)) return false;
