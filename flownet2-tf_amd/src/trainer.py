@@ -246,11 +246,62 @@ class FlowNetSTrainer:
                 self._plan_head(rec)
             else:
                 self._plan_conv(rec)
+        if self.x2 and os.environ.get("FN2_HEAD_MFMA", "1") != "0":
+            for rec in layers:
+                if rec["kind"] == 0 and rec.get("cout") == 2 and rec.get("shared_with") is None:
+                    self._head_forward_gemm(rec)
         self._fuse_act_grads()
         self._plan_zeroing()
         eng._alloc_workspace()  # the input-gradient convolutions share the split-K scratch buffer
         self.refresh_backward_weights()
         self._plan_buckets(4)
+
+    def _head_forward_gemm(self, rec):
+        """Forward of a flow head in the split-fp16 trainer as the engine's inference form (Engine._head_gemm): a 1x1
+        convolution to the 18 (tap, output) partials of a pixel + fn2_flow_head_gather, instead of the wave-per-pixel
+        dot-product kernel.  Its packed weight is one more copy derived from the fp32 master every step."""
+        eng, lib = self.eng, self.lib
+        sbuf, sc0, sc = rec["src"]
+        pf = rec["dst"][0]
+        code = eng._code(sbuf)
+        line = _round_up(sc, 32)
+        if sc0 + line > sbuf.shape[3] or _hip.conv_plan(code, line, 18).layout != 1:
+            return False
+        plan = _hip.conv_plan(code, line, 18)
+        idx = np.zeros((1, 1, sc, 18), np.float64)
+        for tap in range(9):
+            for o in range(2):
+                idx[0, 0, :, tap * 2 + o] = o * rec["kpad"] + tap * rec["cin_pad"] + np.arange(sc)
+        pk, cin_pad, cout_pad, kpad = W.pack_conv(idx + 1.0, plan.cout_tile, plan.kstep_elems, line, plan.layout, dtype=np.float64)
+        gmap = torch.from_numpy((pk.reshape(-1) - 1.0).astype(np.int32)).to(self.dev)
+        wf = torch.zeros(gmap.numel(), dtype=torch.float32, device=self.dev)  # split fp16 in an fp32 container
+        wmax = float(rec["master"].abs().max().item())
+        scale = 2.0 ** int(math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 1.0
+        self.gathers.append((wf, rec["master"], gmap, scale))
+        n, h, w = int(pf.shape[0]), int(pf.shape[1]), int(pf.shape[2])
+        t18 = torch.zeros((n * h * w, 32), dtype=torch.float32, device=self.dev)
+        d = _hip.Fn2ConvDesc()
+        d.inp = self._view(sbuf, sc, sc0)
+        d.out = _hip.Fn2Tensor(t18.data_ptr(), _hip.FN2_F32, n, h, w, 18, 32, 0)
+        d.wgt, d.bias = wf.data_ptr(), None
+        d.kind, d.kh, d.kw, d.stride, d.pad = 0, 1, 1, 1, 0
+        d.act = _hip.ACT_NONE
+        d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, plan.layout
+        d.out_scale = 1.0 / scale
+        eng.conv_descs.append(d)
+        bias = _hip.ptr(rec["b"]) if rec.get("b") is not None else None
+        self.keep += [d, wf, gmap, t18]
+
+        def head_forward(s):
+            return lib.fn2_conv2d(C.byref(d), s) or lib.fn2_flow_head_gather(_hip.ptr(t18), 32, bias, _hip.ptr(pf), n, h, w, s)
+
+        name = f"{rec['scope']}/{rec['name']}"
+        for i, (nm, fn, args) in enumerate(eng.ops):
+            if nm == name and fn is lib.fn2_conv2d and args[0]._obj is rec["desc"]:
+                eng.ops[i] = (nm, head_forward, ())
+                eng.kernel_of[i] = "conv_igemm2_kernel (1x1, 18 partials) + flow_head_gather"
+                return True
+        raise RuntimeError("flow head %s not found in the engine's plan" % name)
 
     def _writes(self, fn, args):
         """[(first byte, end byte, c0, c)] of the activation-gradient buffers a backward launch adds into (4-byte
