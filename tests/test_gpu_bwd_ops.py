@@ -101,3 +101,51 @@ def test_flow_head_gradients_through_g18():
     torch.cuda.synchronize()
     got = dw.cpu().numpy().reshape(2, 3, 3, cin_pad)[..., :cin].transpose(1, 2, 3, 0)
     assert np.abs(got - want).max() < 1.2e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("dtype", ["f16x2", "f32"])
+@pytest.mark.parametrize("k,pad,co,ci,H,W", [(3, 1, 128, 64, 12, 16), (5, 2, 64, 96, 8, 16), (3, 1, 256, 256, 6, 8)])
+def test_input_gradient_of_stride2_conv(dtype, k, pad, co, ci, H, W):
+    """fn2_conv2d kind 3 (the transpose of a k x k stride-2 convolution: four phases that walk only their non-zero tap
+    slots) against the plain scatter dx[n, 2y + ky - p, 2x + kx - p, ci] += dy[n, y, x, co] w[ky, kx, ci, co]."""
+    from src import _hip, weights as Wt
+    lib = _hip.lib()
+    N = 2
+    dy = rnd((N, H, W, co), 90)
+    w = rnd((k, k, ci, co), 91, (2.0 / (k * k * co)) ** 0.5)
+    want = np.zeros((N, 2 * H + k, 2 * W + k, ci), np.float64)   # scatter into a padded frame, then crop
+    for ky in range(k):
+        for kx in range(k):
+            want[:, ky:ky + 2 * H:2, kx:kx + 2 * W:2] += dy.astype(np.float64) @ w[ky, kx].astype(np.float64).T
+    want = want[:, pad:pad + 2 * H, pad:pad + 2 * W]
+    code = 3 if dtype == "f16x2" else 0
+    esz_line = 32
+    cin_pad = (co + esz_line - 1) // esz_line * esz_line
+    plan = _hip.conv_plan(code, cin_pad, ci)
+    if plan.layout != 1:
+        cin_pad = (co + 7) // 8 * 8
+        plan = _hip.conv_plan(code, cin_pad, ci)
+    packed, cin_pad, cout_pad, kpad = Wt.pack_conv_transpose_s2(w, pad, plan.cout_tile, plan.kstep_elems, cin_pad, plan.layout)
+    scale = 1.0
+    if plan.wgt_dtype == 3:
+        k2 = int(np.floor(np.log2(1024.0 / np.abs(packed).max())))
+        packed, scale = packed * 2.0 ** k2, 2.0 ** -k2
+    wdev = Wt.packed_to_device(packed, plan.wgt_dtype, "cuda")
+    yp = np.zeros((N, H, W, cin_pad), np.float32); yp[..., :co] = dy
+    yd = to_dev(yp, dtype)
+    cs_out = (ci + 7) // 8 * 8
+    out = to_dev(np.zeros((N, 2 * H, 2 * W, cs_out), np.float32), dtype)
+    d = _hip.Fn2ConvDesc()
+    d.inp, d.out = _hip.view(yd, co, 0, code), _hip.view(out, ci, 0, code)
+    d.wgt, d.bias = wdev.data_ptr(), None
+    d.kind, d.kh, d.kw, d.stride, d.pad, d.act = 3, k, k, 2, pad, 0
+    d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout, d.out_scale = cin_pad, cout_pad, kpad, plan.layout, scale
+    need = int(lib.fn2_conv2d_workspace_bytes(C.byref(d)))
+    if need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device="cuda")
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    _hip.check(lib.fn2_conv2d(C.byref(d), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    from src import weights as W2
+    got = W2.join_f16x2(out.cpu().numpy().view(np.float16)) if code == 3 else out.cpu().numpy()
+    np.testing.assert_allclose(got[..., :ci], want, rtol=2e-5, atol=2e-5)
