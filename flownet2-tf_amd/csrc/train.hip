@@ -257,43 +257,52 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, float*
   }
 }
 
-// All parameter tensors in one launch: blockIdx.y = tensor, blocks of a row stride its elements.  tab[t] =
-// {w, m, v, g} pointers, n[t] elements, l2[t] regulariser (0 for biases / transposed convs).
-struct AdamTensor { float* w; float* m; float* v; const float* g; };
+// All parameter tensors in one launch: blockIdx.y = tensor, blocks of a row stride its elements four at a time
+// (16-byte accesses; every tensor starts 16-byte aligned).  tab[t] = {w, m, v, g} pointers + the split-fp16 forward
+// copy of the weight (or null) and its power-of-two scale: the copy the convolutions read is written by the same pass
+// that updates the fp32 master.  n[t] elements, l2[t] regulariser (0 for biases / transposed convs).
+struct AdamTensor { float* w; float* m; float* v; const float* g; x2_t* wx2; float scale; int pad_; };
+static_assert(sizeof(AdamTensor) == 48, "the host builds the table as six 64-bit words per tensor");
+__device__ __forceinline__ void adam_tensor(const AdamTensor& t, long cnt, float reg, float lr_t, float b1, float b2,
+                                            float eps, float gscale) {
+  auto one = [&](float wi, float gi, float& mi, float& vi) {
+    gi = gi * gscale + reg * wi;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    return wi - lr_t * mi / (sqrtf(vi) + eps);
+  };
+  const long n4 = cnt >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 w = reinterpret_cast<float4*>(t.w)[i], m = reinterpret_cast<float4*>(t.m)[i], v = reinterpret_cast<float4*>(t.v)[i];
+    const float4 g = reinterpret_cast<const float4*>(t.g)[i];
+    w.x = one(w.x, g.x, m.x, v.x); w.y = one(w.y, g.y, m.y, v.y);
+    w.z = one(w.z, g.z, m.z, v.z); w.w = one(w.w, g.w, m.w, v.w);
+    reinterpret_cast<float4*>(t.m)[i] = m;
+    reinterpret_cast<float4*>(t.v)[i] = v;
+    reinterpret_cast<float4*>(t.w)[i] = w;
+    if (t.wx2 != nullptr) {
+      const float o[4] = {w.x * t.scale, w.y * t.scale, w.z * t.scale, w.w * t.scale};
+      store_vec<x2_t, 4>(t.wx2 + 4 * i, o);
+    }
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
+    float mi = t.m[i], vi = t.v[i];
+    const float wi = one(t.w[i], t.g[i], mi, vi);
+    t.m[i] = mi; t.v[i] = vi; t.w[i] = wi;
+    if (t.wx2 != nullptr) store_elem<x2_t>(t.wx2 + i, wi * t.scale);
+  }
+}
 __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamTensor* __restrict__ tab, const long* __restrict__ n,
                                                          const float* __restrict__ l2, float lr_t, float b1, float b2,
                                                          float eps, float gscale) {
-  const AdamTensor t = tab[blockIdx.y];
-  const long cnt = n[blockIdx.y];
-  const float reg = l2[blockIdx.y];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
-    const float wi = t.w[i];
-    const float gi = t.g[i] * gscale + reg * wi;
-    const float mi = b1 * t.m[i] + (1.f - b1) * gi;
-    const float vi = b2 * t.v[i] + (1.f - b2) * gi * gi;
-    t.m[i] = mi;
-    t.v[i] = vi;
-    t.w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
-  }
+  adam_tensor(tab[blockIdx.y], n[blockIdx.y], l2[blockIdx.y], lr_t, b1, b2, eps, gscale);
 }
 
 // The same with the per-step scalars read from device memory {lr_t, beta1, beta2, eps, grad_scale}: the launch
 // arguments no longer change from step to step, so the whole train step can be replayed as a hipGraph.
 __global__ void __launch_bounds__(256) adam_multi_dev_kernel(const AdamTensor* __restrict__ tab, const long* __restrict__ n,
                                                              const float* __restrict__ l2, const float* __restrict__ hyper) {
-  const AdamTensor t = tab[blockIdx.y];
-  const long cnt = n[blockIdx.y];
-  const float reg = l2[blockIdx.y];
-  const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gscale = hyper[4];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
-    const float wi = t.w[i];
-    const float gi = t.g[i] * gscale + reg * wi;
-    const float mi = b1 * t.m[i] + (1.f - b1) * gi;
-    const float vi = b2 * t.v[i] + (1.f - b2) * gi * gi;
-    t.m[i] = mi;
-    t.v[i] = vi;
-    t.w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
-  }
+  adam_tensor(tab[blockIdx.y], n[blockIdx.y], l2[blockIdx.y], hyper[0], hyper[1], hyper[2], hyper[3], hyper[4]);
 }
 
 // upsample_flowXtoY backward (forward: conv-transpose 2->2, k4 s2 crop 1, upsample_flow_kernel in conv.hip):

@@ -588,7 +588,7 @@ class FlowNetSTrainer:
         return out
 
     # ------------------------------------------------------------------ step
-    def refresh_backward_weights(self):
+    def refresh_backward_weights(self, forward=True):
         """Derive every weight copy the convolutions read from the fp32 masters: the transposed / phase-decomposed
         layouts of the input-gradient convolutions and, in the f16x2 trainer, the split-fp16 forward weights."""
         s = _hip.stream_ptr()
@@ -597,8 +597,9 @@ class FlowNetSTrainer:
                 _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), scale, s))
             else:
                 _hip.check(self.lib.fn2_gather_f32(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), s))
-        for wx2, master, scale in self.fwd_copies:
-            _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wx2), _hip.ptr(master), None, master.numel(), scale, s))
+        if forward:  # (after an Adam step the forward copies are already fresh: fn2_adam_step_multi writes them)
+            for wx2, master, scale in self.fwd_copies:
+                _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wx2), _hip.ptr(master), None, master.numel(), scale, s))
 
     def learning_rate(self, step):
         """Piecewise-constant schedules and the computed policies (CLR, one-cycle, exponential, LR range test):
@@ -711,14 +712,11 @@ class FlowNetSTrainer:
         l2 = self.schedule["l2_regularization"]
         s = _hip.stream_ptr()
         if getattr(self, "_adam_table", None) is None:  # one launch for all parameter tensors
-            ptrs = [[p["w"].data_ptr(), p["m"].data_ptr(), p["v"].data_ptr(), p["g"].data_ptr()] for p in self.params]
-            self._adam_table = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
-            self._adam_counts = torch.tensor([p["n"] for p in self.params], dtype=torch.int64, device=self.dev)
-            self._adam_l2 = torch.tensor([l2 if p["reg"] else 0.0 for p in self.params], dtype=torch.float32, device=self.dev)
+            self._build_adam_tables()
         _hip.check(self.lib.fn2_adam_step_multi(_hip.ptr(self._adam_table), _hip.ptr(self._adam_counts),
                                                 _hip.ptr(self._adam_l2), len(self.params), lr, b1, b2, self.eps,
                                                 self.step_count, 1.0 / (world * self.loss_scale), s))
-        self.refresh_backward_weights()
+        self.refresh_backward_weights(forward=False)
 
     # ------------------------------------------------------------------ validation
     def evaluate(self, batches, max_batches=None):
@@ -847,11 +845,18 @@ class FlowNetSTrainer:
             self._build_adam_tables()
         _hip.check(self.lib.fn2_adam_step_multi_dev(_hip.ptr(self._adam_table), _hip.ptr(self._adam_counts),
                                                     _hip.ptr(self._adam_l2), len(self.params), _hip.ptr(self._hyper), s))
-        self.refresh_backward_weights()
+        self.refresh_backward_weights(forward=False)
 
     def _build_adam_tables(self):
+        """{w, m, v, g, split-fp16 forward copy of w (or 0), its scale} per parameter tensor (fn2_adam_step_multi): Adam
+        rewrites the copy the forward convolutions read while it has the new master in registers."""
         l2 = self.schedule["l2_regularization"]
-        ptrs = [[p["w"].data_ptr(), p["m"].data_ptr(), p["v"].data_ptr(), p["g"].data_ptr()] for p in self.params]
+        fwd = {master.data_ptr(): (wx2.data_ptr(), scale) for wx2, master, scale in self.fwd_copies}
+        ptrs = []
+        for p in self.params:
+            wx2, scale = fwd.get(p["w"].data_ptr(), (0, 1.0))
+            bits = int(np.float32(scale).view(np.uint32))
+            ptrs.append([p["w"].data_ptr(), p["m"].data_ptr(), p["v"].data_ptr(), p["g"].data_ptr(), wx2, bits])
         self._adam_table = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
         self._adam_counts = torch.tensor([p["n"] for p in self.params], dtype=torch.int64, device=self.dev)
         self._adam_l2 = torch.tensor([l2 if p["reg"] else 0.0 for p in self.params], dtype=torch.float32, device=self.dev)

@@ -281,9 +281,10 @@ int fn2_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, 
 int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float lr, float beta1, float beta2,
                   float eps, int step, float l2, float grad_scale, void* stream);
 /* The same update (tf.train.AdamOptimizer.apply_gradients, net.py:1290-1295) for n_tensors parameter tensors in
- * ONE launch.  table: device array of {float* w, float* m,
- * float* v, const float* g} (4 pointers per tensor); counts / l2: device arrays of element counts (int64) and L2
- * coefficients (0 where the reference does not regularise). */
+ * ONE launch.  table: device array of six 64-bit words per tensor: {float* w, float* m, float* v, const float* g,
+ * void* w_f16x2, float scale (low 32 bits)} -- w_f16x2: the split-fp16 copy of w the convolutions read (same packed
+ * geometry), rewritten as w * scale by the same pass, or NULL; every pointer 16-byte aligned.  counts / l2: device
+ * arrays of element counts (int64) and L2 coefficients (0 where the reference does not regularise). */
 int fn2_adam_step_multi(const void* table, const int64_t* counts, const float* l2, int n_tensors, float lr, float beta1,
                         float beta2, float eps, int step, float grad_scale, void* stream);
 /* fn2_adam_step_multi with the per-step scalars in device memory: hyper = {lr_t, beta1, beta2, eps, grad_scale} with
