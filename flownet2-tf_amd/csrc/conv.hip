@@ -950,7 +950,7 @@ static int preferred_split(const ConvArgs& a, int tile, int phases) {
   // as many splits as still give ONE round of resident blocks (2-3 per CU): rounding up put 528 blocks on 512
   // slots for the 12x16-level layers and a second round of 16 stragglers doubled the kernel time
   const char* e = getenv("FN2_SPLIT_SLOTS");  // tuning knob of the experiments behind the default
-  const int slots = e ? atoi(e) : 512;
+  const int slots = e ? atoi(e) : 640;  // (512 until the slab stores were coalesced; FlowNet2 b4: 512 -> 4.29, 640 -> 4.24, 768 / 1024 -> 4.31 / 4.33 ms)
   int s = (int)(slots / blocks);
   const int maxs = a.ksteps / 8;
   if (s > maxs) s = maxs;
