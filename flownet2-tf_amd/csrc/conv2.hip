@@ -987,6 +987,7 @@ __global__ void __launch_bounds__(256) conv_rowrun_kernel(const ConvArgs p, cons
     boff[j] = (q < npieces && Ls < nslots) ? (unsigned)(seg0 + Ls * 16) : kOobOffset;
   }
   const int nl = p.cin_chunks >> 3;   // 128-byte lines per kernel row
+  const int ngroups = (p.KH_KW_hint * p.in_cs + 7) >> 3;   // 8-channel groups of a run that hold pixels (7x7 on 16 channels: 14 of 16)
   auto issue_B = [&](int ky, uint4* lds) {
     const int toff = ky * p.W * p.in_cs * 4;
 #pragma unroll
@@ -1026,6 +1027,7 @@ __global__ void __launch_bounds__(256) conv_rowrun_kernel(const ConvArgs p, cons
       const uint4* A = &ldsA[abuf][fr * 8];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
+        if (4 * l + 2 * q >= ngroups) continue;         // a k-step wholly in the zero padding of the run's last line
         const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
         const int g = 4 * l + 2 * q + fh;               // 8-channel group of the run
         const int sh = pslot + 2 * g, sl = sh + 1;
@@ -1050,6 +1052,12 @@ __global__ void __launch_bounds__(256) conv_rowrun_kernel(const ConvArgs p, cons
   OutT* out = reinterpret_cast<OutT*>(p.out);
   const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
   const int ox = tox + wave * 32 + fr;
+  // the stems write the largest tensors of a step (SD conv0 / fuse_conv0: 200 MB at batch 4): a lane's 16 couts go through
+  // a wave-private LDS tile [32 pixels][32 couts] (the loop's buffers are free, its last barrier has passed) and leave as
+  // whole 128-byte runs, eight pixels per wave instruction (see the epilogue of conv_igemm2_kernel)
+  constexpr int ERS = 36;   // floats per tile row: 32 couts + 16 bytes of padding
+  float* const tl = reinterpret_cast<float*>(&ldsB[0][0]) + wave * (32 * ERS);
+  static_assert(4 * 32 * ERS * 4 <= (int)sizeof(ldsB), "epilogue tiles fit the segment buffers");
 #pragma unroll
   for (int tc = 0; tc < TCN; ++tc) {
     const int cout_base = c0 + tc * 32 + fh * 16;
@@ -1061,7 +1069,16 @@ __global__ void __launch_bounds__(256) conv_rowrun_kernel(const ConvArgs p, cons
       if (p.act == FN2_ACT_LEAKY) x = leaky(x);
       v[q] = x;
     }
-    if (vec16 && cout_base + 15 < p.Cout) {
+    if (sizeof(OutT) == 4 && vec16 && c0 + tc * 32 + 32 <= p.Cout && !(p.dbg & 4194304)) {  // (wave-uniform)
+      store16<OutT>(reinterpret_cast<OutT*>(tl + fr * ERS + fh * 16), v);
+      const int rr = lane >> 3, ch = lane & 7;
+      OutT* ob = out + (((size_t)tn * p.out_H + toy) * p.out_W + tox + wave * 32) * p.out_cs + p.out_c0 + c0 + tc * 32 + ch * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + rr;
+        *reinterpret_cast<uint4*>(ob + (size_t)row * p.out_cs) = *reinterpret_cast<const uint4*>(tl + row * ERS + ch * 4);
+      }
+    } else if (vec16 && cout_base + 15 < p.Cout) {
       store16<OutT>(po, v);
     } else {
 #pragma unroll
