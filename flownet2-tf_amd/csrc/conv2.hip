@@ -765,6 +765,9 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
   // ---- epilogue (as conv_igemm2_kernel): lane (pixel fr of tile tp, half fh) holds couts [16 fh, 16 fh + 16) of tile tc
   OutT* out = reinterpret_cast<OutT*>(p.out);
   const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
+  constexpr int ERS = 36;   // floats per epilogue tile row: 32 couts + 16 bytes of padding
+  static_assert(sizeof(ldsA) >= 4 * 32 * ERS * 4 || sizeof(ldsB) >= 4 * 32 * ERS * 4, "epilogue tiles fit a stage array");
+  float* const etl = reinterpret_cast<float*>(sizeof(ldsA) >= 4 * 32 * ERS * 4 ? &ldsA[0][0] : &ldsB[0][0]) + wave * (32 * ERS);
 #pragma unroll
   for (int tc = 0; tc < TCN; ++tc) {
     const int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
@@ -784,7 +787,19 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = leaky(v[q]);
       }
-      if (vec16 && cout_base + 15 < p.Cout) {
+      if (sizeof(OutT) == 4 && vec16 && c0 + wc * TCN * 32 + tc * 32 + 32 <= p.Cout && !(p.dbg & 4194304)) {
+        // 128-byte runs through a wave-private LDS tile (the loop's last barrier has passed), as in conv_rowrun_kernel
+        store16<OutT>(reinterpret_cast<OutT*>(etl + fr * ERS + fh * 16), v);
+        const int rr = lane >> 3, ch = lane & 7;
+        const int ox0 = tox + wp * TPN * 32 + tp * 32;
+        OutT* ob = out + (((size_t)tn * p.out_H + (toy * osc + oy_off)) * p.out_W + (ox0 * osc + ox_off)) * p.out_cs +
+                   p.out_c0 + c0 + wc * TCN * 32 + tc * 32 + ch * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + rr;
+          *reinterpret_cast<uint4*>(ob + (size_t)row * osc * p.out_cs) = *reinterpret_cast<const uint4*>(etl + row * ERS + ch * 4);
+        }
+      } else if (vec16 && cout_base + 15 < p.Cout) {
         store16<OutT>(po, v);
       } else {
 #pragma unroll
