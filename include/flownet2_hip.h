@@ -301,14 +301,17 @@ int fn2_head_bwd_filter(const fn2_tensor* x, const float* g, float* dw, int cin_
 /* flow head input gradient, ADDED into the view dx: dx[pix][ci] += sum_{tap,co} g[pix-(tap-1)][co] * w[co][tap][ci]. */
 int fn2_head_bwd_data(const float* g, const float* w, const fn2_tensor* dx, int cin_pad, int kpad, void* stream);
 
-/* Filter gradient of one conv layer on the fp32 matrix cores, ADDED into `dw`, which has the layout of the
- * layer's packed forward weight (fn2_conv_desc.wgt: same cin_pad / cout_pad / kpad / wgt_layout).
+/* Filter gradient of one conv layer on the matrix cores (fp32 tensors: fp32 MFMA; split-fp16 tensors: 3 fp16 MFMAs per
+ * product), ADDED into `dw` (fp32, atomics), which has the layout of the layer's packed forward weight
+ * (fn2_conv_desc.wgt: same cin_pad / cout_pad / kpad / wgt_layout).
  *   kind 0: conv            dW[co][tap][ci] += sum x[pix*s + tap - pad][ci] * dy[pix][co]
  *   kind 1: deconv k4 s2    dWt (4-phase packing) += sum x[pix][ci] * dy[2 pix + tap - 1][co]
- *   kind 2: stem row-run conv (x = the pre-padded buffer, pad = 0, cin_pad = run length) */
+ *   kind 2: stem row-run conv (x = the pre-padded buffer, pad = 0, cin_pad = run length)
+ *   kind 4: flow head from fn2_head_g18 (dy = the 18-channel tensor, kh = kw = 3, wgt_layout = 0, cout_pad >= 18):
+ *           dW[o][tap * cin_pad + ci] += sum x[pix][ci] * G18[pix][tap * 2 + o] */
 typedef struct {
-  fn2_tensor x;        /* layer input (fp32) */
-  fn2_tensor dy;       /* gradient wrt the layer's pre-activation output (fp32) */
+  fn2_tensor x;        /* layer input (fp32 or split fp16; dy has the same dtype) */
+  fn2_tensor dy;       /* gradient wrt the layer's pre-activation output */
   float* dw;
   int32_t kind, kh, kw, stride, pad;
   int32_t cin_pad, cout_pad, kpad, wgt_layout;
