@@ -780,15 +780,19 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
     }
   }
   auto issue_uni = [&](float (*lds)[PK * 128]) {
-    const bool ok = u_pix < pend;   // uniform: ranges and the tensor are whole stages
+    // branch-free: offsets are < 2^31 or kOobT = 2^31, so "out of range" is OR-ing the sign bit in.  (Written with ?: and
+    // &&, the compiler built a tree of uniform and exec-mask branches around duplicated DMA instructions.)
+    const unsigned okm = u_pix < pend ? 0u : kOobT;   // uniform: ranges and the tensor are whole stages
+    const int shm1 = p.SH - 1, swm1 = p.SW - 1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = (wave * 4 + k) * 2;
       if (!(FN2_BWF_ABLATE && (p.dbg & 2)))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, ok ? uvd[k] : kOobT, u_soff_d, 0, 0);
-      const bool sv = ok && (unsigned)(u_sy + uiy[k]) < (unsigned)p.SH && (unsigned)(u_sx + uix[k]) < (unsigned)p.SW;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, uvd[k] | okm, u_soff_d, 0, 0);
+      const int ty = u_sy + uiy[k], tx = u_sx + uix[k];
+      const unsigned pad = (unsigned)(ty | (shm1 - ty) | tx | (swm1 - tx)) & kOobT;  // sign bit: a coordinate < 0 or > size - 1
       if (!(FN2_BWF_ABLATE && (p.dbg & 1)))
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_su, (lptr_t)&lds[1][r * 128], 16, sv ? uvs[k] : kOobT, u_soff_s, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_su, (lptr_t)&lds[1][r * 128], 16, uvs[k] | okm | pad, u_soff_s, 0, 0);
     }
     u_pix += PK; u_soff_d += dstep;
     if (p.DW_ >= PK) {
