@@ -828,11 +828,12 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = (wave * 4 + k) * 2;
-      const bool pv = pixd[k] < pend;
-      const unsigned vd = (pv && coff_d[k] != kOobT) ? (unsigned)offd[k] + coff_d[k] : kOobT;
+      // branch-free (see issue_uni): a valid offset is < 2^31, every reason to skip a row sets bit 31
+      const unsigned pvm = (unsigned)(pend - 1 - pixd[k]) & kOobT;   // pixel past the range
+      const unsigned vd = ((unsigned)offd[k] + coff_d[k]) | pvm;      // (coff = 2^31 for a padding chunk)
       if (!(FN2_BWF_ABLATE && (p.dbg & 2))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, vd, 0, 0, 0);
-      const bool sv = pv && coff_s[k] != kOobT && (unsigned)iy[k] < (unsigned)p.SH && (unsigned)ix[k] < (unsigned)p.SW;
-      const unsigned vs = sv ? (unsigned)offs[k] + coff_s[k] : kOobT;
+      const unsigned padm = (unsigned)(iy[k] | (p.SH - 1 - iy[k]) | ix[k] | (p.SW - 1 - ix[k])) & kOobT;
+      const unsigned vs = (((unsigned)offs[k] & ~kOobT) + coff_s[k]) | pvm | padm;
       if (!(FN2_BWF_ABLATE && (p.dbg & 1))) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[1][r * 128], 16, vs, 0, 0, 0);
       pixd[k] += PK; offd[k] += dstep;
       sx[k] += PK; ix[k] += PK * p.stride; offs[k] += xstep;
