@@ -100,6 +100,32 @@ def test_flownet_s_gradients_match_oracle(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model", ["FlowNetS", "FlowNetSD"])
+def test_fused_backward_equals_unfused(model, monkeypatch):
+    """The fusions of the split-fp16 backward pass (LeakyReLU factor in the epilogue of the convolution that completes a
+    gradient slice, first writer stores instead of adding, flow heads through fn2_head_g18 + the matrix-core kernels)
+    against the same trainer with all of them switched off: same loss, every parameter gradient within 1e-5 of the
+    layer's largest."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights(model, 11)
+    a, b, gt = data(2, 128, 192, 5)
+    fused = FlowNetSTrainer(wts, 2, 128, 192, dtype="f16x2", model=model)
+    assert len(fused.fused_act) >= 10 and len(fused._no_zero) >= 5          # the fusions are really on
+    lf = float(fused.forward_backward(a, b, gt).item())
+    gf = {p["name"]: p["g"].clone() for p in fused.params}
+    for k in ("FN2_FUSE_ACT_GRAD", "FN2_SKIP_ZERO", "FN2_HEAD_MFMA"):
+        monkeypatch.setenv(k, "0")
+    plain = FlowNetSTrainer(wts, 2, 128, 192, dtype="f16x2", model=model)
+    assert not plain.fused_act and not plain._no_zero
+    lp = float(plain.forward_backward(a, b, gt).item())
+    assert abs(lf - lp) < 1e-6 * abs(lp)
+    for p in plain.params:
+        want, got = p["g"], gf[p["name"]]
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-12, p["name"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f32", "f16x2"])
 def test_adam_steps_match_oracle(dtype):
     from src import weights as W
