@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(256) head_bwd_data_kernel(const float* __restr
 struct BwdwArgs {
   const float* dn; const float* sm; float* dw;
   int head_kpad, head_cin_pad;         // kind 4 (flow head from G18): row i = (tap, o) goes to (i & 1) * kpad + (i >> 1) * cin_pad; else 0
+  int xcd;                             // bwd_filter_x2_kernel: XCD-aware block order (FN2_BWF_XCD=0: plain)
   int dbg;                             // FN2_BWF_DBG ablation bits (timing experiments; FN2_CONV_ABLATE builds only)
   float* db;                           // bias gradient db[i] += sum_pix Dn[pix][i] (convolutions: Dn = dY), or nullptr
   int N, DH, DW_, dn_cs, dn_c0, Ci;   // dense tensor: [N, DH, DW] pixels, Ci channels of interest
@@ -737,11 +738,23 @@ __global__ void __launch_bounds__(256) bwd_filter_x2_kernel(const BwdwArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1;
   constexpr int TI = 64 * NI, TJ = 64 * NJ;
-  const int i0 = blockIdx.x * TI;
+  // XCD-aware block order (as conv_igemm2_kernel): workgroup L runs on XCD L & 7; give every XCD a contiguous band of the
+  // (pixel range, tap / j tile, i tile) space, pixel range slowest: the blocks of a band read the same pixels (every tap and
+  // tile of a pixel range walks the same dense rows and neighbouring sampled rows), which then meet in that XCD's L2
+  int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  if (p.xcd) {
+    const int NT = gridDim.x * gridDim.y * gridDim.z;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = L & 7, chunk = NT >> 3, rem = NT & 7;
+    int Lp = xcd * chunk + min(xcd, rem) + (L >> 3);
+    bxi = Lp % (int)gridDim.x; Lp /= (int)gridDim.x;
+    byi = Lp % (int)gridDim.y; bzi = Lp / (int)gridDim.y;
+  }
+  const int i0 = bxi * TI;
   const int njt = (p.Cj + TJ - 1) / TJ;
-  const int tap = blockIdx.y / njt, j0 = (blockIdx.y - tap * njt) * TJ;
+  const int tap = byi / njt, j0 = (byi - tap * njt) * TJ;
   const int ky = tap / p.KW, kx = tap - ky * p.KW;
-  const int pbeg = blockIdx.z * p.pix_per_split, pend = min(p.P, pbeg + p.pix_per_split);
+  const int pbeg = bzi * p.pix_per_split, pend = min(p.P, pbeg + p.pix_per_split);
   if (pbeg >= pend) return;
   const int nstage = (pend - pbeg + PK - 1) / PK;
 
@@ -1268,6 +1281,7 @@ int fn2_conv2d_bwd_filter(const fn2_bwdw_desc* d, void* stream) {
   FN2_REQUIRE(d->db == nullptr || d->kind != 1, "bwd_filter: the fused bias gradient sums dy, the dense operand of convolutions only");
   a.db = d->db;
   { const char* e = getenv("FN2_BWF_DBG"); a.dbg = e ? atoi(e) : 0; }
+  { const char* e = getenv("FN2_BWF_XCD"); a.xcd = e ? atoi(e) : 1; }
   a.N = dn->n; a.DH = dn->h; a.DW_ = dn->w; a.dn_cs = dn->cs; a.dn_c0 = dn->c0; a.Ci = dn->c;
   a.SH = sm->h; a.SW = sm->w; a.sm_cs = sm->cs; a.sm_c0 = sm->c0; a.Cj = d->kind == 2 ? d->kw * sm->cs : sm->c;
   const long dnb = (long)dn->n * dn->h * dn->w * dn->cs * 4, smb = (long)sm->n * sm->h * sm->w * sm->cs * 4;
