@@ -584,11 +584,12 @@ __global__ void __launch_bounds__(256) bwd_filter_kernel(const BwdwArgs p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = (wave * 4 + k) * 2;          // first of the 2 rows of this piece (wave-uniform)
-      const bool pv = pixd[k] < pend;
-      const unsigned vd = (pv && ch_ok_d) ? (unsigned)offd[k] : kOobT;
+      // branch-free (see bwd_filter_x2_kernel): a valid offset is < 2^31, every reason to skip a row sets bit 31
+      const unsigned pvm = (unsigned)(pend - 1 - pixd[k]) & kOobT;
+      const unsigned vd = (unsigned)offd[k] | pvm | (ch_ok_d ? 0u : kOobT);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)&lds[0][r * 128], 16, vd, 0, 0, 0);
-      const bool sv = pv && ch_ok_s && (unsigned)iy[k] < (unsigned)p.SH && (unsigned)ix[k] < (unsigned)p.SW;
-      const unsigned vs = sv ? (unsigned)offs[k] : kOobT;
+      const unsigned padm = (unsigned)(iy[k] | (p.SH - 1 - iy[k]) | ix[k] | (p.SW - 1 - ix[k])) & kOobT;
+      const unsigned vs = ((unsigned)offs[k] & ~kOobT) | pvm | padm | (ch_ok_s ? 0u : kOobT);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)&lds[1][r * 128], 16, vs, 0, 0, 0);
       // advance this row by PK pixels for the next stage
       pixd[k] += PK; offd[k] += dstep;
