@@ -46,6 +46,18 @@ def synth_pairs(n, h, w, seed0):
     return np.stack(a_l).astype(np.float32), np.stack(b_l).astype(np.float32)
 
 
+def pad64(x):
+    """Net.adapt_x (net.py:373-388): zero-pad bottom / right to multiples of 64 (1024x436 -> 1024x448)."""
+    n, h, w, c = x.shape
+    return np.pad(x, [(0, 0), (0, -h % 64), (0, -w % 64), (0, 0)])
+
+
+def synth_gt(n, h, w, rank=0):
+    """Ground-truth flow of the train workload: N(0, 5^2) px clipped to +-40."""
+    rng = np.random.default_rng(77 + rank)
+    return np.clip(rng.standard_normal((n, h, w, 2)) * 5, -40, 40).astype(np.float32)
+
+
 def stored_traffic(model, batch, dtype, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
     (tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes).  PMC collection
@@ -106,16 +118,36 @@ def cpu_baseline(model, h, w, seed):
             "sample": "%d pairs %s forward %dx%d one at a time, NumPy fp64 oracle (%.1f s)" % (pairs, model, w, h, total)}
 
 
-def run_train(args, rank, world, dist):
+def cpu_baseline_train(h, w):
+    """The float64 autograd oracle of the train step (loss + all gradients of FlowNetS, one pair at a time) timed on the
+    host cores: bounded sample (>= ~10 s, at most 8 pairs).  Adam is elementwise and not included."""
+    from oracle import train as reft
+    from src import weights as W
+    wts = W.init_weights("FlowNetS", 1234)
+    pairs, total = 0, 0.0
+    while total < 10.0 and pairs < 8:
+        a, b = synth_pairs(1, h, w, pairs)
+        gt = synth_gt(1, h, w, pairs)
+        t0 = time.perf_counter()
+        reft.flownet_s_loss_and_grads(wts, a, b, gt)
+        total += time.perf_counter() - t0
+        pairs += 1
+    return {"value": pairs / total, "unit": "pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d pairs FlowNetS loss + gradients %dx%d one at a time, torch float64 autograd oracle (%.1f s)"
+                      % (pairs, w, h, total)}
+
+
+def run_train(args, rank, world, dist, full=True, batch=None):
     """BASELINE config 4: FlowNetS train step on FlyingChairs-shaped synthetic pairs, `batch` pairs per GPU,
-    data parallel with one RCCL all-reduce of the flat gradient arena per step."""
+    data parallel: the flat gradient arena is all-reduced (RCCL) in 4 buckets under the backward pass, then Adam."""
     from src import _hip, weights as W
     from src.trainer import FlowNetSTrainer
-    tr = FlowNetSTrainer(W.init_weights("FlowNetS", 1234), args.batch, args.height, args.width, dtype=args.train_dtype)
+    batch = batch or args.batch
+    steps = args.steps
+    tr = FlowNetSTrainer(W.init_weights("FlowNetS", 1234), batch, args.height, args.width, dtype=args.train_dtype)
     peak = PEAK_TFLOPS[args.train_dtype]
-    a, b = synth_pairs(args.batch, args.height, args.width, seed0=1000 * rank)
-    rng = np.random.default_rng(77 + rank)
-    gt = np.clip(rng.standard_normal((args.batch, args.height, args.width, 2)) * 5, -40, 40).astype(np.float32)
+    a, b = synth_pairs(batch, args.height, args.width, seed0=1000 * rank)
+    gt = synth_gt(batch, args.height, args.width, rank)
     a, b, gt = (torch.as_tensor(x).cuda() for x in (a, b, gt))  # resident in HBM before the timed region
 
     def barrier():
@@ -126,25 +158,53 @@ def run_train(args, rank, world, dist):
 
     for _ in range(args.warmup):
         tr.train_step(a, b, gt)
+    tr.wait_events = []          # (before, after) event pairs around the bucket waits of every step from here on
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.train_step(a, b, gt)
+    for _ in range(steps):
+        loss = tr.train_step(a, b, gt)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    loss_val = float(loss.item())
+    if not np.isfinite(loss_val):
+        raise RuntimeError("train step produced a non-finite loss")
+    exposed = [e0.elapsed_time(e1) for e0, e1 in tr.wait_events]
+    tr.wait_events = None
+    # ---- the gradient exchange alone: the same buckets, nothing to hide behind (every rank takes part)
+    comm = None
+    if dist is not None:
+        from src.dist import allreduce_bucket_async
+        reps = 5
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            hs = [allreduce_bucket_async(bk) for _, bk in tr.buckets]
+            for h in hs:
+                if h is not None:
+                    h.wait()
+        e1.record()
+        barrier()
+        alone = e0.elapsed_time(e1) / reps
+        nbytes = tr.grad_arena.numel() * 4
+        exp_ms = float(np.mean(exposed)) if exposed else None
+        comm = {"allreduce_ms": round(alone, 4), "allreduce_exposed_ms": None if exp_ms is None else round(exp_ms, 4),
+                "overlap_frac": None if exp_ms is None or alone <= 0 else round(max(0.0, 1.0 - exp_ms / alone), 4),
+                "payload_MB": round(nbytes / 1e6, 1), "buckets": len(tr.buckets),
+                "busbw_GBs": round(2.0 * (world - 1) / world * nbytes / (alone * 1e-3) / 1e9, 1) if alone > 0 else None}
     if rank != 0:
         return None
-    ms_step = dt / args.steps * 1e3
+    ms_step = dt / steps * 1e3
     # ---- per-launch event timing of forward + backward on the launch stream
     flops = dict(tr.eng.layer_flops)
     launches = [(n, fn, ar, k, flops.get(n, 0.0)) for (n, fn, ar), k in zip(tr.eng.ops, tr.eng.kernel_of)]
     launches += tr.backward_launches()
     acc = np.zeros(len(launches))
-    reps = max(1, min(args.steps, 10))
+    reps = max(1, min(steps, 10))
     for _ in range(reps):
         tr.forward_backward(a, b, gt)  # leaves valid gradients for every backward launch to re-run on
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(launches) + 1)]
@@ -169,26 +229,38 @@ def run_train(args, rank, world, dist):
     avg_ms = D["ms"] / D["launches"]
     achieved = (D["flop"] / D["launches"]) / (avg_ms * 1e-3) / 1e12
     total_flop = sum(v["flop"] for v in fams.values())
-    return {
-        "metric": "train pairs/sec at 512x384 (FlowNetS fwd+bwd+Adam)", "value": round(world * args.batch * args.steps / dt, 2),
-        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+    kpeak = PEAK_TFLOPS["f32"] if dom == "bwd_filter_kernel" else peak
+    out = {
+        "metric": "train pairs/sec at 512x384 (FlowNetS fwd+bwd+Adam)", "value": round(world * batch * steps / dt, 2),
+        "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.train_dtype == "f32" else "f16x2 operands (3 fp16 MFMAs per product), fp32 accumulate / masters / Adam",
         "data": "synthetic",
         "config": {"workload": "FlowNetS train step (fwd + multiscale EPE + bwd + Adam), batch=%d synthetic %dx%d pairs "
-                               "per GPU, seeded synthetic weights" % (args.batch, args.width, args.height),
-                   "pairs_per_gpu": args.batch,
-                   "parallelism": "dp%d (one all-reduce of the %.0f MB gradient arena per step)" % (world, tr.grad_arena.numel() * 4 / 1e6)},
+                               "per GPU, seeded synthetic weights" % (batch, args.width, args.height),
+                   "pairs_per_gpu": batch,
+                   "parallelism": "dp%d (the %.0f MB gradient arena all-reduced in %d buckets under the backward pass)"
+                                  % (world, tr.grad_arena.numel() * 4 / 1e6, len(tr.buckets))},
+        "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
+        "backend": (dist.get_backend() if dist is not None else None),
+        "loss": round(loss_val, 6), "output_finite": True,
+        "comm": comm,
         "roofline": {"kernel": dom, "bound": kernel_bound(dom), "achieved": round(achieved, 2),
-                     "peak": PEAK_TFLOPS["f32"] if dom == "bwd_filter_kernel" else peak,
-                     "unit": "TFLOP/s", "frac": round(achieved / (PEAK_TFLOPS["f32"] if dom == "bwd_filter_kernel" else peak), 4),
-                     "traffic": None,
+                     "peak": kpeak, "unit": "TFLOP/s", "frac": round(achieved / kpeak, 4),
+                     "traffic": stored_traffic("FlowNetS_train", batch, args.train_dtype, dom)
+                     if (args.height, args.width) == (384, 512) else None,
                      "launches_per_step": D["launches"], "avg_launch_ms": round(avg_ms, 5),
                      "flop_per_launch": D["flop"] / D["launches"]},
         "kernels": {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"]} for k, v in fams.items()},
         "model_tflops": round(total_flop / (ms_step * 1e-3) / 1e12, 2),
-        "cpu_baseline": None,
+        "step": {"mfma_frac": round(total_flop / (ms_step * 1e-3) / 1e12 / peak, 4)},
     }
+    if not full:
+        for k in ("steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "data", "n_gpus", "kernels"):
+            out.pop(k, None)
+        return out
+    out["cpu_baseline"] = None if (args.no_cpu_baseline or world != 1) else cpu_baseline_train(args.height, args.width)
+    return out
 
 
 def main():
@@ -246,9 +318,15 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # FN2_DIST_SINGLE=1 with --gpus 1: a process group of ONE rank on nccl -- the one-GPU rehearsal of the RCCL call
+    # sequence of the N > 1 run (communicator, barriers, bucketed async all-reduce between the graph segments)
+    if world > 1 or os.environ.get("FN2_DIST_SINGLE") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -275,16 +353,37 @@ def main():
         return
 
     out = forward_line(args, args.model, args.batch, rank, world, dist, full=True)
-    if args.extra and (args.height, args.width) == (384, 512) and (args.model, args.batch) != ("FlowNetC", 8):
-        # BASELINE config 2 in the same process (every rank takes part: same barriers)
-        ex = forward_line(args, "FlowNetC", 8, rank, world, dist, full=False)
+    if args.extra and (args.height, args.width) == (384, 512) and (args.model, args.batch) == ("FlowNet2", 4):
+        # The other workloads BASELINE names, in the same process (every rank takes part: same barriers): configs[1]
+        # FlowNetC batch 8, the metric's third model FlowNetS (batch 8) and configs[3], the FlowNetS train step with 8
+        # pairs per GPU -- for N > 1 that is the one path with a collective (bucketed gradient all-reduce over RCCL)
+        extra = {}
+        for key, model in (("FlowNetC_b8", "FlowNetC"), ("FlowNetS_b8", "FlowNetS")):
+            extra[key] = forward_line(args, model, 8, rank, world, dist, full=False)
+        torch.cuda.empty_cache()
+        extra["FlowNetS_train_b8"] = run_train(args, rank, world, dist, full=False, batch=8)
         if rank == 0:
-            out["extra"] = {"FlowNetC_b8": ex}
+            out["extra"] = extra
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def golden_epe(model, batch, h, w, dtype, flow):
+    """Mean endpoint error (px) of the timed plan's flow field against the oracle probes committed for exactly this
+    workload (tests/golden/plan_<model>_b<batch>_<h>x<w>.npz, rank-0 inputs); None when no fixture exists for it."""
+    path = os.path.join(ROOT, "tests", "golden", "plan_%s_b%d_%dx%d.npz" % (model.lower(), batch, h, w))
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    f = flow.float().cpu().numpy()[:, g["probe_y"], g["probe_x"]].astype(np.float64)
+    d = f - g["flow"].astype(np.float64)
+    e = float(np.sqrt((d * d).sum(-1)).mean())
+    if dtype in ("f32", "f16x2") and not e < 1e-3:
+        raise RuntimeError("%s b%d: mean EPE vs the oracle fixture %.3e px exceeds the 1e-3 px parity bar" % (model, batch, e))
+    return float("%.3e" % e)
 
 
 def kernel_bound(kernel):
@@ -329,8 +428,15 @@ def forward_line(args, model, batch, rank, world, dist, full):
     dt = float(np.median(region_s))  # the reported region: K steps, max over ranks, median over the repeats
     ms_step = dt / args.steps * 1e3
     pairs_s = world * batch * args.steps / dt
+    # ---- what was timed is what is checked: the flow field of the last replay must be finite on every rank, and on
+    # rank 0 (whose inputs are the ones tests/golden/make_golden_bench_plans.py used) it is compared with the committed
+    # oracle probes of this very plan -- data files, no oracle code runs here
+    flow = eng.outputs["flow"]
+    if not bool(torch.isfinite(flow).all().item()):
+        raise RuntimeError("%s b%d: non-finite values in the flow field after the timed regions" % (model, batch))
     if rank != 0:
         return None
+    fixture_epe = golden_epe(model, batch, args.height, args.width, args.dtype, flow)
 
     # ---- per-kernel event timing on the launch stream (eager, same K steps)
     graph, eng.graph = eng.graph, None
@@ -339,12 +445,14 @@ def forward_line(args, model, batch, rank, world, dist, full):
     fams = {}
     flops = dict(eng.layer_flops)
     nbytes = dict(eng.layer_bytes)
+    iobytes = dict(eng.layer_io_bytes)
     for (name, fn, _), kern, ms in zip(eng.ops, eng.kernel_of, per_op):
-        d = fams.setdefault(kern, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0})
+        d = fams.setdefault(kern, {"ms": 0.0, "launches": 0, "flop": 0.0, "bytes": 0.0, "io": 0.0})
         d["ms"] += ms
         d["launches"] += 1
         d["flop"] += flops.get(name, 0.0)
         d["bytes"] += nbytes.get(name, 0.0)
+        d["io"] += iobytes.get(name, 0.0)
     if args.per_layer:
         for (name, fn, _), ms in zip(eng.ops, per_op):
             fl = flops.get(name, 0.0)
@@ -358,7 +466,10 @@ def forward_line(args, model, batch, rank, world, dist, full):
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype],
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
                     "launches_per_step": D["launches"], "avg_launch_ms": round(avg_ms, 5),
-                    "flop_per_launch": D["flop"] / D["launches"]}
+                    "flop_per_launch": D["flop"] / D["launches"],
+                    # input slice + output slice + weights of the layers this instantiation runs, once each
+                    "algorithmic_bytes_per_launch": round(D["io"] / D["launches"]),
+                    "traffic_over_algorithmic": None if not traffic or not D["io"] else round(traffic / (D["io"] / D["launches"]), 3)}
     else:
         gbs = (D["bytes"] / D["launches"]) / (avg_ms * 1e-3) / 1e9 if D["bytes"] else None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": None if gbs is None else round(gbs, 1), "peak": HBM_PEAK_GBS,
@@ -384,6 +495,12 @@ def forward_line(args, model, batch, rank, world, dist, full):
         "roofline": roofline, "kernels": kernels,
         "model_gflop_per_pair": round(eng.flops_per_forward / batch / 1e9, 3),
         "model_tflops": round(eng.flops_per_forward * args.steps / dt / 1e12, 2),
+        # the step as a whole against both roofs: algorithmic FLOP over the MFMA peak of the dtype; every layer's input +
+        # output + weights once (plus the HBM-bound ops' SURVEY 8d bytes) over the HBM peak
+        "step": {"mfma_frac": round(eng.flops_per_forward / (ms_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                 "hbm_frac": round((sum(iobytes.values()) + sum(nbytes.values())) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "algorithmic_GB": round((sum(iobytes.values()) + sum(nbytes.values())) / 1e9, 3)},
+        "output_finite": True, "epe_vs_oracle_fixture_px": fixture_epe,
         "reference_k80_ms_per_pair": K80_MS.get(model),
         "speedup_vs_reference_k80": round(K80_MS[model] / (ms_step / batch), 1) if model in K80_MS else None,
     }

@@ -6,8 +6,17 @@ section 2: no distributed code), so this module has no counterpart there.
 
 torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def exchange_enabled():
+    """True when gradients are exchanged: a process group with more than one rank -- or, FN2_DIST_SINGLE=1, with a
+    single rank (a one-GPU rehearsal that drives the identical RCCL call sequence: communicator, bucketed
+    all_reduce(async_op=True) on RCCL's stream between the captured graph segments, waits)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("FN2_DIST_SINGLE") == "1")
 
 
 def shard_range(n_items, rank, world):
@@ -40,7 +49,7 @@ def allreduce_gradients(flat):
     """SUM the flat fp32 gradient arena over all ranks, in place (one collective per step: the arena is a
     single contiguous buffer, ~155 MB for FlowNetS, so the ring runs at xGMI link bandwidth rather than
     launch latency).  The 1/world mean is folded into the Adam kernel's grad_scale.  Returns world size."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not exchange_enabled():
         return 1
     if flat.is_cuda and dist.get_backend() == "gloo":  # CPU-rendezvous tests of the GPU trainer
         host = flat.cpu()
@@ -56,7 +65,7 @@ def allreduce_bucket_async(bucket):
     there is nothing to wait for).  Called from inside the backward pass as soon as the slice is complete, so
     the ring runs on RCCL's stream under the remaining backward kernels (c10d orders it after the producing
     kernels of the current stream)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not exchange_enabled():
         return None
     if bucket.is_cuda and dist.get_backend() == "gloo":  # CPU-rendezvous tests: synchronous staging
         host = bucket.cpu()

@@ -120,6 +120,10 @@ class Engine:
         self.bufs = {}
         self.layer_flops = []  # (name, flop) algorithmic, for roofline accounting
         self.layer_bytes = []  # (name, bytes) algorithmic HBM bytes of the HBM-bound ops
+        # (name, bytes) of every convolution: its input slice read once + its output slice written once + its weights
+        # read once, in the engine's storage formats (SURVEY.md 8d's accounting per layer) -- what `roofline.traffic`
+        # (PMC) is compared with
+        self.layer_io_bytes = []
         self.in_a = torch.zeros((self.N, self.H, self.W, 3), dtype=torch.float32, device=self.device)
         self.in_b = torch.zeros_like(self.in_a)
         self.uint8_inputs = bool(uint8_inputs)
@@ -318,6 +322,9 @@ class Engine:
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         taps = k * k if kind == "conv" else 4
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * taps * cin * cout))
+        osz = 4 if dbuf.dtype == torch.float32 else 2
+        self.layer_io_bytes.append((f"{scope}/{name}", float(sbuf.shape[0] * sbuf.shape[1] * sbuf.shape[2] * cin * esz
+                                                            + n * oh * ow * cout * osz + k * k * cin * cout * esz)))
 
     def _head_gemm(self, scope, spec, src, dst):
         """predict_flowN as a GEMM: 1x1 convolution with 18 outputs (tap*2 + co) on the LDS-DMA kernel into a shared
@@ -367,6 +374,7 @@ class Engine:
         self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(head_t), 32,
                  _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd)
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
+        self.layer_io_bytes.append((f"{scope}/{name}", float(n * h * wd * (cin * esz + 2 * 4) + 18 * cin * esz)))
         return True
 
     def _conv_stem(self, scope, spec, sbuf, dst, s2d=False):
@@ -424,6 +432,8 @@ class Engine:
                  kernel=f"conv_igemm2_kernel<{tn}, {tn}, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1, tn == 'fn2::x2_t')}>")
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * k_alg * k_alg * cin_alg * cout))
+        self.layer_io_bytes.append((f"{scope}/{name}", float(sbuf.numel() * esz + n * oh * ow * cout * esz
+                                                            + k_alg * k_alg * cin_alg * cout * esz)))
 
     def _upflow(self, scope, name, src_f32, dst):
         dbuf, dc0, dc = dst

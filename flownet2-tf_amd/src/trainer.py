@@ -862,9 +862,9 @@ class FlowNetSTrainer:
         self._adam_l2 = torch.tensor([l2 if p["reg"] else 0.0 for p in self.params], dtype=torch.float32, device=self.dev)
 
     def _capture_step(self):
-        from .dist import world_size
+        from .dist import exchange_enabled
         # one segment per gradient bucket when the gradients are exchanged, else a single backward segment
-        self._seg_ends = [i for i, _ in self.buckets] if world_size() > 1 else [len(self.bwd_ops) - 1]
+        self._seg_ends = [i for i, _ in self.buckets] if exchange_enabled() else [len(self.bwd_ops) - 1]
         self._gts = torch.empty_like(self.gt)
         self._labels = {pname: torch.empty_like(self.eng.outputs[pname]) for pname in self.loss_terms}
         for pname in self.loss_terms:
@@ -892,7 +892,7 @@ class FlowNetSTrainer:
         self._step_graphs = graphs
 
     def _train_step_graph(self, input_a, input_b, gt_flow):
-        from .dist import allreduce_bucket_async, world_size
+        from .dist import allreduce_bucket_async, exchange_enabled, world_size
         if getattr(self, "_step_graphs", None) is None:
             self._capture_step()
         self.gt.copy_(torch.as_tensor(gt_flow).to(dtype=torch.float32), non_blocking=True)
@@ -915,11 +915,18 @@ class FlowNetSTrainer:
         pending = []
         for i in range(len(self._seg_ends)):
             _hip.check(self.lib.fn2_graph_launch(self._step_graphs[i], s))
-            if world > 1:
+            if exchange_enabled():
                 h = allreduce_bucket_async(self.buckets[i][1])
                 if h is not None:
                     pending.append(h)
+        timed = pending and getattr(self, "wait_events", None) is not None
+        if timed:  # bench.py: how long the compute stream sits in the bucket waits (the part of the exchange backward did not hide)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in pending:
             h.wait()
+        if timed:
+            e1.record()
+            self.wait_events.append((e0, e1))
         _hip.check(self.lib.fn2_graph_launch(self._step_graphs[-1], s))
         return self.loss_dev
