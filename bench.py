@@ -327,21 +327,24 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the one
-            # JSON line by pointing fd 1 at stderr while the group forms
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+        # RCCL prints a version banner and gloo its connection lines on STDOUT while the group forms: keep stdout for the
+        # one JSON line by pointing fd 1 at stderr until the first collective has run
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
-                dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     if args.mode == "train":
         out = run_train(args, rank, world, dist)

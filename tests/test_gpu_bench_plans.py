@@ -115,42 +115,64 @@ def _reference_layout(tr, p):
 
 @pytest.mark.parametrize("dtype", ["f16x2", "f32"])
 def test_timed_train_plan_gradients_match_oracle(golden_dir, dtype):
-    """BASELINE config 4, one rank's shard: FlowNetS at 8 x 384 x 512 exactly as bench.run_train builds it.  Loss and
-    ALL parameter gradients (flownet_s.py:122-161 under tf.gradients) against the committed float64 autograd answers:
-    every bias gradient in full, >= 2048 entries of every filter gradient incl. its 64 largest.  Tolerance 2e-5 of the
-    layer's largest gradient, as at the reduced sizes of tests/test_gpu_train.py -- but the oracle here could not be told
-    which LeakyReLU branch the device took for pre-activations within fp32 rounding of 0 (no device in the build
-    container), so elements whose gradient differs by exactly such a flip are bounded separately: 5e-5."""
+    """BASELINE config 4, one rank's shard: FlowNetS at 8 x 384 x 512 exactly as bench.run_train builds it; loss and ALL
+    parameter gradients (flownet_s.py:122-161 under tf.gradients) of that plan.
+
+    (1) Against the committed float64-autograd answers (every bias gradient in full, >= 2048 entries of every filter
+        gradient incl. its 64 largest; no oracle run needed).  The loss, and the flow heads' gradients (products of the loss
+        gradient and forward activations only), are held to 2e-5.  Every other tensor sits behind LeakyReLUs whose
+        pre-activations land within fp32 rounding of 0 for a handful of the step's 1e8 elements: device and float64
+        take different branches of the kink there (slopes 1 and 0.1) and one such element at the 6x8 level moves every
+        gradient upstream of it -- the container had no device to ask which branch it took -- so those tensors are only
+        bounded: median <= 2e-4, max <= 1e-2 of the tensor's largest entry (measured: 5e-5 / 2e-3).
+    (2) Exactly: the same oracle re-run on this box, pair by pair, differentiating the branch the device took
+        (oracle.train `signs`, as tests/test_gpu_train.py does at reduced size): EVERY entry of EVERY gradient within
+        2e-5 of the tensor's largest (4e-5 for the four 64-entry upsample_flow filters, whose entries are fp32 sums over
+        up to 1e5 pixels; measured 8e-6 / 1.8e-5)."""
+    from oracle import train as reft
     from src import weights as W
     from src.trainer import FlowNetSTrainer
+    from test_gpu_train import device_signs
     g = np.load(os.path.join(golden_dir, "plan_flownets_train_b8_384x512.npz"))
     a, b, gt = _train_inputs(8, 384, 512)
-    tr = FlowNetSTrainer(W.init_weights("FlowNetS", 1234), 8, 384, 512, dtype=dtype)
+    wts = W.init_weights("FlowNetS", 1234)
+    tr = FlowNetSTrainer(wts, 8, 384, 512, dtype=dtype)
     loss = float(tr.forward_backward(a, b, gt).item())
     want_loss = float(g["loss"])
-    print("loss %.6f, oracle %.6f" % (loss, want_loss))
+    print("loss %.6f, committed oracle loss %.6f" % (loss, want_loss))
     assert abs(loss - want_loss) < 2e-5 * abs(want_loss)
-    kern = {k for _, _, _, k, _ in tr.backward_launches()} | set(tr.eng.kernel_of)
-    _SEEN["train_" + dtype] = kern
-    worst = 0.0
-    for p in tr.params:
-        got = _reference_layout(tr, p)
-        name = p["name"]
+    _SEEN["train_" + dtype] = {k for _, _, _, k, _ in tr.backward_launches()} | set(tr.eng.kernel_of)
+    got = {p["name"]: _reference_layout(tr, p) for p in tr.params}
+    # ---- (1) the committed fixture
+    for name, gv in got.items():
         if name in g.files:
-            want = np.asarray(g[name], np.float64).reshape(-1)
-            gotv = got.reshape(-1).astype(np.float64)
+            want, gotv = np.asarray(g[name], np.float64).reshape(-1), gv.reshape(-1).astype(np.float64)
             scale = np.abs(want).max() + 1e-30
         else:
-            idx = g[name + "#idx"]
-            want = g[name + "#val"]
-            assert tuple(g[name + "#shape"]) == got.shape, name
-            gotv = got.reshape(-1)[idx].astype(np.float64)
-            scale = float(g[name + "#max"])
-        err = float(np.abs(gotv - want).max() / scale)
-        print("  %-40s %6d entries  max err / max |g| = %.2e" % (name, want.size, err))
+            assert tuple(g[name + "#shape"]) == gv.shape, name
+            want, gotv, scale = g[name + "#val"], gv.reshape(-1)[g[name + "#idx"]].astype(np.float64), float(g[name + "#max"])
+        e = np.abs(gotv - want) / scale
+        if "/predict_flow" in name:
+            assert e.max() < 2e-5, (name, e.max())
+        else:
+            assert np.median(e) < 2e-4 and e.max() < 1e-2, (name, np.median(e), e.max())
+    # ---- (2) the oracle on the device's LeakyReLU branches
+    signs = device_signs(tr)
+    grads, oloss = None, 0.0
+    for i in range(8):
+        l, gr, _ = reft.flownet_s_loss_and_grads(wts, a[i:i + 1], b[i:i + 1], gt[i:i + 1],
+                                                 signs={k: v[i:i + 1] for k, v in signs.items()})
+        oloss += l / 8
+        grads = {k: v / 8 for k, v in gr.items()} if grads is None else {k: grads[k] + v / 8 for k, v in gr.items()}
+    assert abs(loss - oloss) < 2e-5 * abs(oloss)
+    worst = 0.0
+    for name, gv in got.items():
+        want = grads[name]
+        err = float(np.abs(gv.reshape(-1) - want.reshape(-1)).max() / (np.abs(want).max() + 1e-30))
+        print("  %-40s %8d entries  max err / max |g| = %.2e" % (name, want.size, err))
+        assert err < (4e-5 if "upsample_flow" in name else 2e-5), name
         worst = max(worst, err)
-        assert err < 5e-5, name
-    print("max relative gradient error over all parameters: %.2e" % worst)
+    print("max relative gradient error over all parameters of the batch-8 plan: %.2e" % worst)
 
 
 def test_timed_train_step_equals_eager_and_moves_the_weights():
@@ -168,13 +190,18 @@ def test_timed_train_step_equals_eager_and_moves_the_weights():
         le = float(eag.forward_backward(a, b, gt).item())
         eag.apply_gradients()
         assert np.isfinite(lc) and abs(lc - le) <= 1e-5 * abs(le), (lc, le)
-    moved = 0
+    moved, frac_worst = 0, 0.0
     for pc, pe, w_init in zip(cap.params, eag.params, w0):
-        d = float((pc["w"] - pe["w"]).abs().max())
-        # fp32 atomics of the filter gradients reorder between runs: Adam's m / sqrt(v) turns a 1e-6 relative change
-        # of a gradient into at most ~1e-6 of lr = 1e-4 per step
-        assert d <= 1e-8 + 1e-6 * float(pe["w"].abs().max()), (pc["name"], d)
+        d = (pc["w"] - pe["w"]).abs()
+        # The fp32 atomics of the filter gradients reorder between runs (1e-6 relative).  Adam's first steps move a
+        # weight by ~lr * g / |g|: for the few entries whose gradient is itself of the size of that noise the step's sign
+        # is undetermined, so single entries may differ by up to 2 steps * 2 lr; all the others agree to 1e-6
+        assert float(d.max()) <= 4.1e-4, (pc["name"], float(d.max()))
+        frac = float((d > 1e-6).float().mean())
+        frac_worst = max(frac_worst, frac)
+        assert frac < 0.01, (pc["name"], frac)
         moved += int(float((pc["w"] - w_init).abs().max()) > 0)
+    print("captured vs eager after two Adam steps: at most %.4f %% of a tensor's entries differ by more than 1e-6" % (100 * frac_worst))
     assert moved == len(cap.params)
 
 
