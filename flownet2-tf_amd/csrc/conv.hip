@@ -563,6 +563,166 @@ __global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __re
   }
 }
 
+// Flow-head tail in ONE launch: the gather above generalised to NT x NT taps (3: predict_flowN; 5: a linear interconvN
+// composed with its predict_flowN, see fn2_flow_head_tail in flownet2_hip.h) and followed, in the same block, by
+// upsample_flowXtoY (4x4 stride-2 transposed conv on the two flow channels, flownet_s.py:60-63) into the 2-channel
+// slice of the next concat buffer.  A block owns TY x TX flow pixels: the partials of the tile + (NT/2 + UP) halo go
+// through LDS in coalesced runs, the flow is formed on the tile + UP halo (the transposed conv reads a 1-pixel
+// neighbourhood; halo pixels are recomputed by the neighbouring blocks rather than exchanged), the tile itself is
+// written as fp32 [n,h,w,2], and the 2TY x 2TX upsampled pixels leave as one (hi, lo) pair of 4-byte stores each.
+// `ring`: the image's outermost pixel ring was written to `pf` beforehand by head_ring_kernel (a composed head's
+// border pixels use other weights) -- it is read from there instead of being gathered.
+// Tap order of the sums = the existing kernels': ky outer, kx inner from the bias; ty outer, tx inner for the upsample.
+template <int NT, int TY, int TX, bool UP, typename OutT>
+__global__ void __launch_bounds__(256) head_tail_kernel(const float* __restrict__ t, int t_cs, const float* __restrict__ bias,
+                                                        float* __restrict__ pf, int N, int H, int W, int ring,
+                                                        const float* __restrict__ up_w, const float* __restrict__ up_bias,
+                                                        OutT* __restrict__ up, int up_cs, int up_c0) {
+  constexpr int R = NT / 2, E = UP ? 1 : 0, HALO = R + E;
+  constexpr int RW = TX + 2 * HALO, RH = TY + 2 * HALO, NTAP = NT * NT;
+  constexpr int EW = TX + 2 * E, EH = TY + 2 * E;
+  __shared__ float2 sm[RH * RW * NTAP];
+  __shared__ float2 spf[EH * EW];
+  __shared__ float sw[64];
+  const int tid = threadIdx.x;
+  if (UP && tid < 64) sw[tid] = up_w[tid];  // [ky][kx][o][i]
+  const int tiles_x = (W + TX - 1) / TX, tiles_y = (H + TY - 1) / TY;
+  const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+  for (int blk = blockIdx.x; blk < N * tiles_y * tiles_x; blk += gridDim.x) {
+    const int tx = blk % tiles_x, ty = (blk / tiles_x) % tiles_y, n = blk / (tiles_x * tiles_y);
+    const int x0 = tx * TX - HALO, y0 = ty * TY - HALO;
+    for (int idx = tid; idx < RH * RW * NTAP; idx += 256) {
+      const int p = idx / NTAP, j = idx - p * NTAP;
+      const int hy = p / RW, hx = p - hy * RW;
+      const int gy = y0 + hy, gx = x0 + hx;
+      float2 v = make_float2(0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const float2*>(t + (((long)n * H + gy) * W + gx) * t_cs + 2 * j);
+      sm[idx] = v;
+    }
+    __syncthreads();
+    // flow on the tile + E halo
+    for (int e = tid; e < EH * EW; e += 256) {
+      const int ey = e / EW, ex = e - ey * EW;
+      const int oy = ty * TY - E + ey, ox = tx * TX - E + ex;
+      float a0 = 0.f, a1 = 0.f;
+      if (oy >= 0 && oy < H && ox >= 0 && ox < W) {
+        const bool inner = ey >= E && ey < E + TY && ex >= E && ex < E + TX;  // this block's own pixels
+        float2* po = reinterpret_cast<float2*>(pf + (((long)n * H + oy) * W + ox) * 2);
+        if (ring && (oy == 0 || oy == H - 1 || ox == 0 || ox == W - 1)) {
+          const float2 v = *po;
+          a0 = v.x; a1 = v.y;
+        } else {
+          a0 = b0; a1 = b1;
+#pragma unroll
+          for (int ky = 0; ky < NT; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < NT; ++kx) {
+              const float2 v = sm[((ey + ky) * RW + ex + kx) * NTAP + ky * NT + kx];
+              a0 += v.x; a1 += v.y;
+            }
+          if (inner) *po = make_float2(a0, a1);
+        }
+      }
+      spf[e] = make_float2(a0, a1);  // zeros outside the image: the transposed conv has no taps there
+    }
+    if constexpr (UP) {
+      __syncthreads();
+      const float ub0 = up_bias ? up_bias[0] : 0.f, ub1 = up_bias ? up_bias[1] : 0.f;
+      for (int o = tid; o < 4 * TY * TX; o += 256) {
+        const int uy = o / (2 * TX), ux = o - uy * (2 * TX);
+        const int oy = 2 * ty * TY + uy, ox = 2 * tx * TX + ux;
+        if (oy >= 2 * H || ox >= 2 * W) continue;
+        const int a = uy & 1, b = ux & 1, y = uy >> 1, x = ux >> 1;   // tile-local flow pixel
+        float r0 = ub0, r1 = ub1;
+#pragma unroll
+        for (int tty = 0; tty < 2; ++tty) {
+          const int iy = y - 1 + a + tty, ky = 3 - a - 2 * tty;
+          const int gy = ty * TY + iy;
+          if (gy < 0 || gy >= H) continue;
+#pragma unroll
+          for (int ttx = 0; ttx < 2; ++ttx) {
+            const int ix = x - 1 + b + ttx, kx = 3 - b - 2 * ttx;
+            const int gx = tx * TX + ix;
+            if (gx < 0 || gx >= W) continue;
+            const float2 v = spf[(iy + E) * EW + ix + E];
+            const float* ww = sw + (ky * 4 + kx) * 4;
+            r0 += v.x * ww[0] + v.y * ww[1];
+            r1 += v.x * ww[2] + v.y * ww[3];
+          }
+        }
+        OutT* po = up + (((size_t)n * 2 * H + oy) * 2 * W + ox) * up_cs + up_c0;
+        if constexpr (is_x2<OutT>::value) {
+          // channels (c0, c0 + 1) of one 8-channel group, c0 even: the two hi halves are 4 bytes, the two lo halves too
+          const size_t addr = reinterpret_cast<size_t>(po);
+          _Float16* g = reinterpret_cast<_Float16*>(addr & ~size_t(31));
+          const int j = (int)((addr & 31) >> 2);
+          typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+          const _Float16 h0 = (_Float16)r0, h1 = (_Float16)r1;
+          *reinterpret_cast<h2*>(g + j) = h2{h0, h1};
+          *reinterpret_cast<h2*>(g + 8 + j) = h2{(_Float16)(r0 - (float)h0), (_Float16)(r1 - (float)h1)};
+        } else {
+          store_elem<OutT>(po, r0);
+          store_elem<OutT>(po + 1, r1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Border ring of a COMPOSED head (fn2_flow_head_tail, taps = 5).  With ic = interconv(x) (3x3, pad 1, bias b1, linear) and
+// pf = predict_flow(ic) (3x3, pad 1, bias b2, linear), the reference zero-pads ic before the second conv
+// (flownet_sd.py:60-63: pad(interconv)), so for a pixel p on the image's outermost ring the taps t of the second conv
+// with p + t outside the image must NOT see interconv evaluated there.  The composed 5x5 weights therefore depend on
+// which borders p touches: case = 3 * cy + cx, c in {0: low border, 1: interior, 2: high border}, and
+//   pf(p) = bc[case] + sum_{u in 5x5, ci} wc[case][u][ci][o] x(p + u)[ci]        (x zero outside the image)
+// One wave per ring pixel, lanes stride the (tap, 8-channel group) items, shuffle reduction: the flow_head_kernel form.
+// (Images with H or W < 3 make a pixel touch both borders of an axis; the host refuses those.)
+__global__ void __launch_bounds__(256) head_ring_kernel(const x2_t* __restrict__ in, int in_cs, int in_c0, int cin_groups,
+                                                        const float* __restrict__ wc, const float* __restrict__ bc,
+                                                        float* __restrict__ pf, int N, int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int ring = 2 * W + 2 * (H - 2);
+  const int nitems = 25 * cin_groups;
+  const size_t case_stride = (size_t)nitems * 8 * 2;  // floats per case: [tap][ci][o]
+  for (long m = wave; m < (long)N * ring; m += nwaves) {
+    const int n = (int)(m / ring), r = (int)(m - (long)n * ring);
+    int y, x;
+    if (r < W) { y = 0; x = r; }
+    else if (r < 2 * W) { y = H - 1; x = r - W; }
+    else { const int q = r - 2 * W; y = 1 + (q >> 1); x = (q & 1) ? W - 1 : 0; }
+    const int cy = y == 0 ? 0 : (y == H - 1 ? 2 : 1), cx = x == 0 ? 0 : (x == W - 1 ? 2 : 1);
+    const int cs = 3 * cy + cx;
+    const float* w = wc + (size_t)cs * case_stride;
+    float a0 = 0.f, a1 = 0.f;
+    for (int q = lane; q < nitems; q += 64) {
+      const int tap = q / cin_groups, gi = q - tap * cin_groups;
+      const int ky = tap / 5, kx = tap - ky * 5;
+      const int iy = y + ky - 2, ix = x + kx - 2;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const uint4* src = reinterpret_cast<const uint4*>(in + (((size_t)n * H + iy) * W + ix) * in_cs + in_c0 + gi * 8);
+      float xv[8];
+      join8(src[0], src[1], xv);
+      const float* u = w + (size_t)q * 16;   // [ci 0..7][o 0..1]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0 += xv[j] * u[2 * j];
+        a1 += xv[j] * u[2 * j + 1];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64);
+      a1 += __shfl_xor(a1, off, 64);
+    }
+    if (lane == 0)
+      *reinterpret_cast<float2*>(pf + (((size_t)n * H + y) * W + x) * 2) = make_float2(a0 + bc[2 * cs], a1 + bc[2 * cs + 1]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // upsample_flowXtoY: 2 -> 2 channel transposed conv 4x4 s2 crop 1, linear (flownet_s.py:60-63; bias only in
 // the FlowNet2 fusion net, flownet2.py:70-73, :86-89).  HBM-bound: one lane per output pixel.
@@ -697,6 +857,33 @@ static int pack_imgs(const float* i0, const float* i1, const fn2_tensor* out, in
   return FN2_OK;
 }
 
+template <int NT, int TY, int TX, typename OutT>
+void launch_head_tail(bool up, const float* t, int t_cs, const float* bias, float* pf, int n, int h, int w, int ring,
+                      const float* up_w, const float* up_bias, void* up_data, int up_cs, int up_c0, hipStream_t s) {
+  const long tiles = (long)n * ((h + TY - 1) / TY) * ((w + TX - 1) / TX);
+  const dim3 grid((unsigned)std::min<long>(tiles, 1 << 16)), block(256);
+  if (up)
+    hipLaunchKernelGGL((head_tail_kernel<NT, TY, TX, true, OutT>), grid, block, 0, s, t, t_cs, bias, pf, n, h, w, ring, up_w,
+                       up_bias, (OutT*)up_data, up_cs, up_c0);
+  else
+    hipLaunchKernelGGL((head_tail_kernel<NT, TY, TX, false, float>), grid, block, 0, s, t, t_cs, bias, pf, n, h, w, ring,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, 0);
+}
+template <typename OutT>
+void launch_head_tail_t(int taps, bool up, const float* t, int t_cs, const float* bias, float* pf, int n, int h, int w,
+                        int ring, const float* up_w, const float* up_bias, void* up_data, int up_cs, int up_c0,
+                        hipStream_t s) {
+  // big maps: 8-row tiles (less halo per flow pixel); small ones: 4 x 32 tiles so that a 48 x 64 level still has ~100 blocks
+  const long big = (long)n * ((h + 7) / 8) * ((w + 63) / 64);
+  if (taps == 3) {
+    if (big >= 256) launch_head_tail<3, 8, 64, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+    else launch_head_tail<3, 4, 32, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+  } else {
+    if (big >= 256) launch_head_tail<5, 8, 32, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+    else launch_head_tail<5, 4, 32, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+  }
+}
+
 }  // namespace fn2
 
 using namespace fn2;
@@ -772,8 +959,14 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   fn2_conv_plan plan;
   rc = fn2_conv2d_plan(d->in.dtype, d->cin_pad, d->out.c, &plan);
   if (rc) return rc;
-  FN2_REQUIRE(d->wgt_layout == plan.layout, "conv2d: wgt_layout %d does not match fn2_conv2d_plan (%d)", d->wgt_layout,
-              plan.layout);
+  // wgt_layout 2 = layout 1's packed matrix re-tiled into MFMA-fragment order (conv2.hip, WREG): 128-cout split-fp16 layers
+  const bool wfrag = d->wgt_layout == 2;
+  if (wfrag)
+    FN2_REQUIRE(plan.layout == 1 && plan.cout_tile >= 64 && d->in.dtype == FN2_F16X2 && d->kind != 2,
+                "conv2d: wgt_layout 2 (fragment order) is for split-fp16 layers with more than 32 output channels");
+  else
+    FN2_REQUIRE(d->wgt_layout == plan.layout, "conv2d: wgt_layout %d does not match fn2_conv2d_plan (%d)", d->wgt_layout,
+                plan.layout);
   const int tile = plan.cout_tile;
   FN2_REQUIRE(d->cout_pad % tile == 0 && d->cout_pad >= d->out.c, "conv2d: cout_pad must be a multiple of the cout tile");
   FN2_REQUIRE(d->act == FN2_ACT_NONE || d->act == FN2_ACT_LEAKY, "conv2d: bad activation");
@@ -785,6 +978,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
 
   ConvArgs& a = *out;
   a.KH_KW_hint = 0;
+  a.wfrag = wfrag ? 1 : 0;   // (2 = the 3-slot ring form, chosen below)
   a.in = d->in.data; a.wgt = d->wgt; a.bias = d->bias; a.out = d->out.data;
   a.N = d->in.n; a.H = d->in.h; a.W = d->in.w; a.in_cs = d->in.cs; a.in_c0 = d->in.c0;
   a.cin_chunks = d->cin_pad / CH;
@@ -872,7 +1066,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = (a.Cout + 3) / 4 * 4;
   { const char* e = getenv("FN2_CONV_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.in_bytes = 0;
-  if (d->wgt_layout == 1) {
+  if (d->wgt_layout >= 1) {
     // the LDS-DMA kernel addresses both operands through buffer descriptors with 32-bit byte offsets
     const long in_bytes = (long)d->in.n * d->in.h * d->in.w * d->in.cs * esz;
     FN2_REQUIRE(in_bytes < (1L << 31), "conv2d: input buffer >= 2 GiB is not addressable by the LDS-DMA kernel");
@@ -888,10 +1082,20 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     const int mode = e ? atoi(e) : 2;
     a.wmajor = mode == 2 ? (A * (double)(X < 8 ? X : 8) + B > A + B * (double)(Y < 8 ? Y : 8)) : mode;
   }
-  a.bp64 = wants_bp64(a, tile, phases, d->wgt_layout) ? 1 : 0;
+  a.bp64 = wfrag ? 1 : wants_bp64(a, tile, phases, d->wgt_layout) ? 1 : 0;
   // experiment (bit 64): weight-streaming 128-cout layers (the ones left on 128 x 128 + split-K) on 128 x 64 tiles
   // with the 3-slot ring
   if ((a.dbg & 64) && d->wgt_layout == 1 && tile == 128 && !a.bp64) a.bp64 = 2;
+  // (fragment-order weights, wgt_layout 2: always the plain 128 x 64 grid of the WREG kernel -- every choice below is for layout 1)
+  if (wfrag) {
+    // FN2_WREG_RING: 0 = two-stage loop; 1 (default) = the 3-slot ring on one-round grids (384 .. FN2_RING_MAX blocks, as
+    // for layout 1); 2 = the ring everywhere
+    const char* e_wr = getenv("FN2_WREG_RING");
+    const char* e_ring = getenv("FN2_RING_MAX");
+    const int mode = e_wr ? atoi(e_wr) : 1;
+    const long blocks = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * phases;
+    if (tile == 128 && (mode == 2 || (mode == 1 && blocks >= 384 && blocks <= (e_ring ? atoi(e_ring) : 512)))) a.wfrag = 2;
+  }
   // 128 x 64 layers whose grid is at most two blocks per CU and takes no split-K (384..512 blocks: conv4_1 / deconv3
   // at batch 8, conv3 / conv3_1 at batch 4): the 3-slot ring's 72 KB of LDS costs them no resident block and keeps
   // two stages of DMA in flight instead of one (+4..7 %; with a third resident block to lose it is 5-12 % slower).
@@ -916,11 +1120,26 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
       else if (blocks <= (e2 ? atoi(e2) : 95)) { a.bp64 = 1; a.kg = 2; }
     }
   }
+  // Deep ring (conv2.hip, STAGES = 6): 128 x 64 grids of about one block per CU or less.  A single resident block has no
+  // neighbour to hide its DMA round trips, so the two-stage loop runs at one round trip per stage there and the layer
+  // was split over K to get more blocks (slabs + a finalize launch); five stages of DMA in flight per block stream at the
+  // L2 -> LDS rate instead.  FN2_DEEP_MIN / FN2_DEEP_MAX = the grid sizes (blocks) that take it.
+  if (d->wgt_layout == 1 && tile == 128 && !(a.dbg & 32) && d->in.dtype == FN2_F16X2) {
+    const char* e_lo = getenv("FN2_DEEP_MIN");
+    const char* e_hi = getenv("FN2_DEEP_MAX");
+    const long blocks = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * phases;
+    const int lo = e_lo ? atoi(e_lo) : 0, hi = e_hi ? atoi(e_hi) : -1;
+    if (blocks >= lo && blocks <= hi) { a.bp64 = 3; a.kg = 1; }
+  }
   if (d->wgt_layout == 1 && tile == 128 && a.bp64 == 1 && a.kg == 1) {
     const char* e_ring = getenv("FN2_RING_MAX");  // tuning knob (read per launch: tools/ab_conv.py toggles it in-process)
     const int ring_max = e_ring ? atoi(e_ring) : 512;
     const long blocks = (long)cdiv(a.M, 64) * (a.cout_pad / 128) * phases;
     if ((a.dbg & 256) || (blocks >= 384 && blocks <= ring_max)) a.bp64 = 2;
+    // experiment (FN2_RING_SPLIT = smallest grid): split-K layers on the ring as well, split so that the grid is one round
+    // of two resident blocks per CU (512 slots) instead of three two-stage blocks (640 slots)
+    const char* e_rs = getenv("FN2_RING_SPLIT");
+    if (e_rs && blocks >= atoi(e_rs) && blocks < 384) a.bp64 = 2;
   }
   *tile_out = tile;
   *phases_out = phases;
@@ -934,6 +1153,17 @@ static int preferred_split(const ConvArgs& a, int tile, int phases) {
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
   const char* e_min = getenv("FN2_SPLIT_MINBLOCKS");  // tuning knob: grids from this many blocks up take no split-K
   if (blocks >= (e_min ? atoi(e_min) : 384)) return 1;
+  if (a.bp64 == 3) {
+    // deep ring: one block per CU streams by itself; split only to reach about FN2_DEEP_SLOTS blocks
+    const char* e_sl = getenv("FN2_DEEP_SLOTS");
+    int s = (int)((e_sl ? atoi(e_sl) : 256) / blocks);
+    const int maxs = a.ksteps / 16;
+    if (s > maxs) s = maxs;
+    if (s > 16) s = 16;
+    if (s < 2) return 1;
+    const int kper = cdiv(a.ksteps, s);
+    return cdiv(a.ksteps, kper);
+  }
   if (a.kg > 1) {
     // K-group blocks hold a CU each (96 / 144 KB of LDS): one round = 256 blocks; a group wants >= 6 stages
     const char* e_nos = getenv("FN2_KG_NOSPLIT");  // grids from this many blocks up take no split
@@ -950,7 +1180,8 @@ static int preferred_split(const ConvArgs& a, int tile, int phases) {
   // as many splits as still give ONE round of resident blocks (2-3 per CU): rounding up put 528 blocks on 512
   // slots for the 12x16-level layers and a second round of 16 stragglers doubled the kernel time
   const char* e = getenv("FN2_SPLIT_SLOTS");  // tuning knob of the experiments behind the default
-  const int slots = e ? atoi(e) : 640;  // (512 until the slab stores were coalesced; FlowNet2 b4: 512 -> 4.29, 640 -> 4.24, 768 / 1024 -> 4.31 / 4.33 ms)
+  const char* e_rsl = getenv("FN2_RING_SPLIT_SLOTS");
+  const int slots = (tile == 128 && a.bp64 == 2) ? (e_rsl ? atoi(e_rsl) : 512) : e ? atoi(e) : 640;  // (512 until the slab stores were coalesced; FlowNet2 b4: 512 -> 4.29, 640 -> 4.24, 768 / 1024 -> 4.31 / 4.33 ms)
   int s = (int)(slots / blocks);
   const int maxs = a.ksteps / 8;
   if (s > maxs) s = maxs;
@@ -980,7 +1211,7 @@ int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d) {
 int fn2_conv2d_kernel_name(const fn2_conv_desc* d, char* name, int cap) {
   FN2_REQUIRE(name && cap > 0, "conv2d_kernel_name: no buffer");
   name[0] = 0;
-  if (!d || d->wgt_layout != 1 || is_flow_head(d)) return FN2_OK;  // only the LDS-DMA launchers report their choice
+  if (!d || d->wgt_layout < 1 || is_flow_head(d)) return FN2_OK;  // only the LDS-DMA launchers report their choice
   conv_name_sink() = ConvNameSink{name, cap};
   const int rc = fn2_conv2d(d, nullptr);
   conv_name_sink() = ConvNameSink{nullptr, 0};
@@ -1023,7 +1254,7 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     a.splitk = sk;
     a.ws = reinterpret_cast<float*>(d->workspace);
   }
-  if (d->wgt_layout == 1) {
+  if (d->wgt_layout >= 1) {
     // LDS-DMA kernel: a stage is two generic k-steps (the tap never changes inside a stage)
     a.ksteps = a.ksteps / 2;
     a.kper = cdiv(a.kper, 2);
@@ -1066,6 +1297,48 @@ int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out
     hipLaunchKernelGGL(flow_head_gather_small_kernel, dim3(grid_for((long)n * h * w, 256)), dim3(256), 0,
                        (hipStream_t)stream, t, t_cs, bias, out, n, h, w);
   FN2_CHECK_LAUNCH("flow_head_gather");
+  return FN2_OK;
+}
+
+int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, float* pf, int n, int h, int w, int ring,
+                       const float* up_w, const float* up_bias, const fn2_tensor* up_out, void* stream) {
+  FN2_REQUIRE(t && pf, "flow_head_tail: null pointer");
+  FN2_REQUIRE(taps == 3 || taps == 5, "flow_head_tail: taps must be 3 or 5");
+  FN2_REQUIRE(t_cs >= 2 * taps * taps && t_cs % 2 == 0 && n >= 1 && h >= 1 && w >= 1,
+              "flow_head_tail: t must hold 2 * taps^2 partials per pixel");
+  FN2_REQUIRE(!ring || (h >= 3 && w >= 3), "flow_head_tail: a border ring needs h, w >= 3");
+  const bool up = up_w != nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (!up) {
+    launch_head_tail_t<float>(taps, false, t, t_cs, bias, pf, n, h, w, ring, nullptr, nullptr, nullptr, 0, 0, s);
+  } else {
+    int rc = check_view(up_out, "flow_head_tail upsample output");
+    if (rc) return rc;
+    FN2_REQUIRE(up_out->c == 2 && up_out->n == n && up_out->h == 2 * h && up_out->w == 2 * w,
+                "flow_head_tail: the upsample view must be [n, 2h, 2w, 2]");
+    if (up_out->dtype == FN2_F16X2) FN2_REQUIRE(up_out->c0 % 2 == 0, "flow_head_tail: split-fp16 slice must start at an even channel");
+    void* d = up_out->data;
+    if (up_out->dtype == FN2_F32) launch_head_tail_t<float>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+    else if (up_out->dtype == FN2_F16X2) launch_head_tail_t<x2_t>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+    else if (up_out->dtype == FN2_BF16) launch_head_tail_t<bf16_t>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+    else launch_head_tail_t<f16_t>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+  }
+  FN2_CHECK_LAUNCH("flow_head_tail");
+  return FN2_OK;
+}
+
+int fn2_flow_head_ring(const fn2_tensor* x, const float* wc, const float* bc, float* pf, void* stream) {
+  int rc = check_view(x, "flow_head_ring input");
+  if (rc) return rc;
+  FN2_REQUIRE(wc && bc && pf, "flow_head_ring: null pointer");
+  FN2_REQUIRE(x->dtype == FN2_F16X2 && x->cs % 8 == 0 && x->c0 % 8 == 0, "flow_head_ring: split-fp16 input, 8-aligned view");
+  FN2_REQUIRE(x->h >= 3 && x->w >= 3, "flow_head_ring: h, w >= 3");
+  const int groups = (x->c + 7) / 8;
+  FN2_REQUIRE(x->c0 + groups * 8 <= x->cs, "flow_head_ring: the last 8-channel group reaches past the buffer");
+  const long ring = (long)x->n * (2 * x->w + 2 * (x->h - 2));
+  hipLaunchKernelGGL(head_ring_kernel, dim3(grid_for(ring * 64, 256)), dim3(256), 0, (hipStream_t)stream, (const x2_t*)x->data,
+                     x->cs, x->c0, groups, wc, bc, pf, x->n, x->h, x->w);
+  FN2_CHECK_LAUNCH("flow_head_ring");
   return FN2_OK;
 }
 

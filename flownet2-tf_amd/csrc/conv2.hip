@@ -54,6 +54,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr unsigned kOobOffset = 0x80000000u;  // >= num_records of every descriptor (tensors < 2 GiB)
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));   // a 16-byte register quad as inline-asm operand
 
 // raw buffer descriptor: base, stride 0, num_records bytes, raw dword format
 __device__ __forceinline__ v4i_t make_rsrc(const void* base, int bytes) {
@@ -87,7 +88,17 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
 // M16 = the 16x16x32 matrix instruction instead of 32x32x16 (split-fp16 operands only; A/B experiment of the guide's
 // "the chip can hold a higher clock on one MFMA shape than on the other"): same LDS image, same fragment reads per
 // FLOP; a lane then holds runs of 4 consecutive output channels instead of 16.
-template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2, int KG = 1, bool M16 = false>
+// WREG = the weight operand never touches LDS: the host stores it in MFMA-FRAGMENT order (wgt_layout 2: per 32-cout tile
+// and 128-byte stage four 1 KiB blocks {q = 0, 1} x {hi, lo}, lane-linear, so a wave's fragment is ONE fully coalesced
+// 16-byte-per-lane load) and every wave loads the fragments of its own 32 couts straight into registers one stage
+// ahead; only the pixel rows go through LDS-DMA.  The wave layout that goes with it is WC = 4 x WP = 1 (a wave owns 32
+// couts x the whole pixel tile: no weight byte is fetched twice).  Against the 2 x 2 layout of the same 128 x 64 tile:
+// LDS-DMA pieces per wave and stage 6 -> 2 (their issue cost, ~60-180 cycles each, is what a wave spends besides its
+// 384 cycles of MFMAs), LDS writes 24 -> 8 KB and fragment reads 48 -> 32 KB per stage, the same 24 KB through L1.
+// SLAB (WREG instantiations only) = the launch is a K split: the epilogue is the partial-sum slab store and nothing else
+// (without it a WREG instantiation has no slab code at all); the other instantiations decide at run time.
+template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2, int KG = 1, bool M16 = false,
+          bool WREG = false, bool SLAB = false>
 __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
@@ -96,22 +107,35 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   static_assert(WC * WP == 4, "4 waves per block");
   constexpr int NWI = BC / 32;  // weight-row DMA pieces per wave per stage (8 rows each)
   constexpr int NPI = BP / 32;  // pixel-row DMA pieces per wave per stage
-  constexpr int ROWS = BC + BP;
+  static_assert(!WREG || (is_x2<T>::value && TCN == 1 && KG == 1 && (STAGES == 2 || STAGES == 3) && !M16),
+                "WREG: split fp16, one cout tile per wave, two-stage loop or 3-slot ring");
+  constexpr int BOFF = WREG ? 0 : BC;           // first pixel row inside a stage buffer
+  // WREG: the stage buffers hold pixel rows only (BP x 128 B each) and all of them live in ONE pool together with the
+  // epilogue's wave tiles ([32 TPN pixels][TCN 32 + 4 words] + offsets per wave, two waves per half of the pool): the
+  // pool is max(STAGES stage buffers, 4 wave tiles); ROWS = rows of HALF the pool (what the epilogue's region test sees)
+  constexpr int kWTileBytes = (32 * TPN * (TCN * 32 + 4) + 32 * TPN) * 4;
+  constexpr int kPoolHalfRows = (STAGES * BP * 128 / 2 > 2 * kWTileBytes ? STAGES * BP * 128 / 2 : 2 * kWTileBytes) / 128 + 1;
+  constexpr int ROWS = WREG ? kPoolHalfRows : BC + BP;
   // two separate LDS objects, not lds[2][..]: the waitcnt pass only lets a ds_read run ahead of an in-flight
   // LDS-DMA when it can prove (alias scopes of distinct LDS variables) that they touch different objects; with
   // one array and a runtime buffer index it put s_waitcnt vmcnt(0) in front of every stage's first ds_read,
   // i.e. the "prefetch" of stage s+1 was waited for BEFORE the MFMAs of stage s.
   static_assert(KG == 1 || STAGES == 2, "K groups run the two-stage loop");
-  __shared__ uint4 lds0_all[KG * ROWS * 8];
-  __shared__ uint4 lds1_all[KG * ROWS * 8];
-  __shared__ uint4 lds2[STAGES == 3 ? ROWS * 8 : 1];
+  // STAGES > 3: one ring of STAGES slots (the DMA is inline asm, so the compiler's waitcnt pass sees no LDS writes and a
+  // runtime slot index costs nothing); the epilogue's scratch tiles then live in its first two slots
+  constexpr bool kDeep = STAGES > 3;
+  __shared__ uint4 lds0_all[(kDeep ? STAGES : WREG ? 2 : KG) * ROWS * 8];
+  __shared__ uint4 lds1_all[(kDeep || WREG) ? 1 : KG * ROWS * 8];
+  __shared__ uint4 lds2_own[(STAGES == 3 && !WREG) ? ROWS * 8 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = KG > 1 ? wave_all >> 2 : 0;   // K group of this wave
   const int wave = KG > 1 ? wave_all & 3 : wave_all;
   uint4* const lds0 = lds0_all + grp * (ROWS * 8);
-  uint4* const lds1 = lds1_all + grp * (ROWS * 8);
+  uint4* const lds1 = WREG ? lds0_all + BP * 8 : kDeep ? lds0_all + ROWS * 8 : lds1_all + grp * (ROWS * 8);
+  uint4* const lds2 = WREG ? lds0_all + 2 * BP * 8 : lds2_own;
+  uint4* const ep1 = (kDeep || WREG) ? lds0_all + ROWS * 8 : lds1_all;   // second scratch region of the epilogue
   const int wc = wave / WP, wp = wave % WP;
 
   int pad_y = p.pad, pad_x = p.pad, oy_off = 0, ox_off = 0, osc = 1;
@@ -203,15 +227,33 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   auto issue_piece = [&](auto piece_c, uint4* lds) {
     constexpr int i = decltype(piece_c)::value;
     if constexpr (i < NWI) {
-      if (!(FN2_CONV_ABLATE && (p.dbg & 2)))
-        dma16(rsrc_w, &lds[(wave * (BC / 4) + i * 8) * 8], woff[i], ((ky * p.KW + kx) * spt + sc) * 128);
+      if constexpr (!WREG) {
+        if (!(FN2_CONV_ABLATE && (p.dbg & 2)))
+          dma16(rsrc_w, &lds[(wave * (BC / 4) + i * 8) * 8], woff[i], ((ky * p.KW + kx) * spt + sc) * 128);
+      }
     } else {
       constexpr int j = i - NWI;
       const unsigned tbit = (1u << ky) | (1u << (8 + kx));
       const int toff = ((ky * p.W + kx) * p.in_cs + sc * 8 * CH) * ESZ;
       const unsigned voff = ((vmask[j] & tbit) == tbit && wstage < kt1) ? (unsigned)(roff[j] + toff) : kOobOffset;
       if (!(FN2_CONV_ABLATE && (p.dbg & 1)))
-        dma16(rsrc_x, &lds[(BC + wave * (BP / 4) + j * 8) * 8], voff, 0);
+        dma16(rsrc_x, &lds[(BOFF + wave * (BP / 4) + j * 8) * 8], voff, 0);
+    }
+  };
+  // WREG: this wave's weight fragments of one stage, loaded by inline asm (the compiler must neither wait for them nor
+  // count them: guide 5.7 item 1, form ii -- every consumer sits behind a wait statement that names the registers)
+  u32x4_t wfa[WREG ? 4 : 1], wfb[WREG ? 4 : 1], wfc[(WREG && STAGES == 3) ? 4 : 1];
+  const unsigned wlane = (unsigned)lane * 16u;
+  const int wtile_off = WREG ? ((c0 >> 5) + wc) * (p.ksteps * 4096) : 0;   // byte offset of this wave's 32-cout tile
+  auto load_w = [&](u32x4_t (&wf)[WREG ? 4 : 1]) {
+    if constexpr (WREG) {
+      const int soff = wtile_off + ((ky * p.KW + kx) * spt + sc) * 4096;
+      asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen\n\t"
+                   "buffer_load_dwordx4 %1, %4, %5, %6 offen offset:1024\n\t"
+                   "buffer_load_dwordx4 %2, %4, %5, %6 offen offset:2048\n\t"
+                   "buffer_load_dwordx4 %3, %4, %5, %6 offen offset:3072"
+                   : "=&v"(wf[0]), "=&v"(wf[1]), "=&v"(wf[2]), "=&v"(wf[3])
+                   : "v"(wlane), "s"(rsrc_w), "s"(soff) : "memory");
     }
   };
   auto advance1 = [&]() {
@@ -236,6 +278,17 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
       (issue_piece(std::integral_constant<int, I>{}, lds), ...);
     }(std::make_integer_sequence<int, NWI + NPI>{});
     advance();
+  };
+  auto issue_stage_w = [&](uint4* lds, u32x4_t (&wf)[WREG ? 4 : 1]) {   // WREG: pixel DMA + this wave's weight fragments
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      (issue_piece(std::integral_constant<int, I>{}, lds), ...);
+    }(std::make_integer_sequence<int, NWI + NPI>{});
+    load_w(wf);
+    advance();
+  };
+  auto wait_w = [&](u32x4_t (&wf)[WREG ? 4 : 1]) {   // everything in flight has landed; the fragments may be read from here on
+    if constexpr (WREG)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) :: "memory");
   };
 
   // ---- fragment addresses: row r = l&31 of a 32-row tile, chunk 2*ks + (l>>5), swizzled by the row
@@ -355,13 +408,73 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
 #endif
   };
 
+  // WREG: the A fragments of the stage are the registers wf[2 q + {0: hi, 1: lo}]; B as above
+  auto compute_w = [&](const uint4* lds, const u32x4_t (&wf)[WREG ? 4 : 1]) {
+    if constexpr (WREG) {
+#if FN2_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      const uint4* B = &lds[(BOFF + wp * TPN * 32 + fr) * 8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
+        uint4 bh[TPN], bl[TPN];
+#pragma unroll
+        for (int t = 0; t < TPN; ++t) { bh[t] = B[t * 32 * 8 + chh]; bl[t] = B[t * 32 * 8 + chl]; }
+#pragma unroll
+        for (int tp = 0; tp < TPN; ++tp) {
+          const uint4 ah = __builtin_bit_cast(uint4, wf[2 * q]), al = __builtin_bit_cast(uint4, wf[2 * q + 1]);
+          acc[0][tp] = mfma_32x32x16<f16_t>(al, bh[tp], acc[0][tp]);
+          acc[0][tp] = mfma_32x32x16<f16_t>(ah, bl[tp], acc[0][tp]);
+          acc[0][tp] = mfma_32x32x16<f16_t>(ah, bh[tp], acc[0][tp]);
+        }
+      }
+#if FN2_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+  };
+
   // NOTE: nothing conditional may wrap the MFMAs: an `if` around them made hipcc shuttle all 64
   // accumulators between VGPRs and AGPRs four times per stage (256 v_accvgpr moves, the dominant VALU
   // cost of the first version of this loop -- found with SQ_INSTS_VALU and the .s).
   // Two stages per trip so that every LDS access names its object statically (see the lds0/lds1 note), and no
   // branch between them: an odd stage count is rounded up with a stage whose pixel rows are all zero (the
   // validity test in issue_piece fails for stages >= kt1), so its MFMAs add 0 * stale finite weights.
-  if constexpr (STAGES == 2) {
+  if constexpr (WREG && STAGES == 3) {
+    // 3-slot ring of pixel stages (8 KB each) + three register sets of weight fragments: per stage, wait until all but the
+    // newest stage's 6 vector-memory instructions of this wave (2 DMA pieces + 4 fragment loads) are done, bare barrier,
+    // refill the slot and the register set of the stage computed last with the stage two ahead
+    static_assert(NPI + 4 == 6, "vmcnt literal below");
+    auto ring_sync_w = [&](u32x4_t (&wf)[4]) {
+      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) :: "memory");
+    };
+    issue_stage_w(lds0, wfa);
+    issue_stage_w(lds1, wfb);
+    const int nst3 = (kt1 - kt0 + 2) / 3 * 3;
+    for (int s = 0; s < nst3; s += 3) {
+      ring_sync_w(wfa); issue_stage_w(lds2, wfc); compute_w(lds0, wfa);
+      ring_sync_w(wfb); issue_stage_w(lds0, wfa); compute_w(lds1, wfb);
+      ring_sync_w(wfc); issue_stage_w(lds1, wfb); compute_w(lds2, wfc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wfa[0]), "+v"(wfa[1]), "+v"(wfa[2]), "+v"(wfa[3]), "+v"(wfb[0]), "+v"(wfb[1]),
+                 "+v"(wfb[2]), "+v"(wfb[3]) :: "memory");  // the look-ahead stages (zero pixel rows) have landed before the registers die
+  } else if constexpr (WREG) {
+    issue_stage_w(lds0, wfa);
+    wait_w(wfa);
+    __syncthreads();
+    const int nst2 = (kt1 - kt0 + 1) & ~1;
+    for (int s = 0; s < nst2; s += 2) {
+      issue_stage_w(lds1, wfb);
+      compute_w(lds0, wfa);
+      wait_w(wfb);
+      __syncthreads();
+      if (s + 2 < nst2) issue_stage_w(lds0, wfa);
+      compute_w(lds1, wfb);
+      wait_w(wfa);
+      __syncthreads();
+    }
+  } else if constexpr (STAGES == 2) {
     // (On the MFMA-bound layers a 3-slot ring was measured 20-30 % slower with 128 x 128 tiles: 96 KB of LDS = one
     // block per CU, and losing the second block's MFMAs under this block's waits costs more than the deeper
     // prefetch gains.)
@@ -380,6 +493,28 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+  } else if constexpr (kDeep) {
+    // Deep ring for grids of about one block per CU (a single resident block has nothing else to hide its DMA round
+    // trips behind): STAGES slots, D = STAGES - 1 stages of DMA in flight, counted vmcnt -- never 0 inside the loop --
+    // and a bare s_barrier per stage.  Iteration s: wait until this wave's pieces of stage s have landed (all but the
+    // 6 (D - 1) youngest), barrier (every wave's pieces of stage s are in LDS, and every wave has finished reading the
+    // slot of stage s - 1), refill that slot with stage s + D, compute stage s.  Stages past the end are zero stages
+    // (out-of-range pixel rows), so the loop has no tail code; they are drained after it.
+    constexpr int ND = NWI + NPI, D = STAGES - 1;
+    static_assert(ND * (D - 1) <= 63, "vmcnt field");
+    auto slot_ptr = [&](int sl) { return lds0_all + sl * (ROWS * 8); };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue_stage(slot_ptr(d));
+    const int nst = kt1 - kt0;
+    int rd = 0, wr = D;   // slot read by this iteration / refilled in it
+    for (int s = 0; s < nst; ++s) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(ND * (D - 1)) : "memory");
+      issue_stage(slot_ptr(wr));
+      compute(slot_ptr(rd));
+      rd = rd + 1 == STAGES ? 0 : rd + 1;
+      wr = wr + 1 == STAGES ? 0 : wr + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     // Ring: per stage, wait until all but the newest stage's ND DMA instructions of this wave have landed, bare
     // s_barrier (every wave's rows of stage s are in LDS, and every wave is done reading slot (s+2)%3, the slot of
@@ -492,19 +627,20 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   OutT* out = reinterpret_cast<OutT*>(p.out);
   // wave-private LDS tile [pixel][cout] of the epilogues below (the stage buffers are free by now)
   constexpr int WCOLS = TCN * 32, RS = WCOLS + 4, WROWS = 32 * TPN;   // row stride padded: 16 lanes x float4 hit 16 bank groups
-  constexpr int WREG = WROWS * RS + WROWS;                            // 4-byte words per wave: tile + one offset per row
-  constexpr bool kLdsT = (KG > 1 ? 4 : 2) * WREG * 4 <= KG * ROWS * 128;
+  constexpr int WTW = WROWS * RS + WROWS;                             // 4-byte words per wave: tile + one offset per row
+  constexpr bool kLdsT = (KG > 1 ? 4 : 2) * WTW * 4 <= KG * ROWS * 128;
   // K groups: the reduction scratch lives in lds0_all and other waves may still be reading it -> all four in lds1_all
-  float* const tl = reinterpret_cast<float*>(KG > 1 ? lds1_all : (wave < 2 ? lds0_all : lds1_all)) + (KG > 1 ? wave : (wave & 1)) * WREG;
+  float* const tl = reinterpret_cast<float*>(KG > 1 ? ep1 : (wave < 2 ? lds0_all : ep1)) + (KG > 1 ? wave : (wave & 1)) * WTW;
   constexpr int CPR = WCOLS / 4, RPI = 64 / CPR;   // 16-byte chunks per tile row, rows per wave instruction
-  if (p.splitk > 1) {
+  static_assert(!SLAB || WREG, "SLAB is a specialisation of the WREG instantiations");
+  if ((SLAB || !WREG) && p.splitk > 1) {
     float* slab = p.ws + (size_t)split * p.N * p.out_H * p.out_W * p.ws_cs;
     // The accumulators of a lane are 16 consecutive couts of ONE pixel: stored directly, a wave instruction writes 64
     // separate 16-byte pieces (one per pixel row of the slab).  Through a wave-private LDS tile [pixel][cout] the same
     // instruction count writes whole 256-byte runs (16 lanes per pixel row): measured 8-11 % of the kernel on the
     // split layers (tools/ab_conv.py, FN2_CONV_DBG bit 2097152 of the ablation build).
     if constexpr (kLdsT) {
-      if constexpr (STAGES == 3) __syncthreads();  // the ring ends without a barrier: other waves may still read their last slot
+      if constexpr (STAGES >= 3) __syncthreads();  // the ring ends without a barrier: other waves may still read their last slot
       int* rowoff = reinterpret_cast<int*>(tl + WROWS * RS);
 #pragma unroll
       for (int tp = 0; tp < TPN; ++tp) {
@@ -553,12 +689,13 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     }
     return;
   }
+  if constexpr (SLAB) return;
   const bool vec16 = (p.out_cs % 8 == 0) && (p.out_c0 % 8 == 0);
   // 4-byte outputs whose whole wave tile lies inside the view: the finished 16-byte chunks go through the wave's LDS
   // tile and leave as whole (TCN x 128)-byte runs of a pixel, like the split-K slabs above (wave-uniform choice)
   const bool wide = kLdsT && sizeof(OutT) == 4 && vec16 && c0 + wc * WCOLS + WCOLS <= p.Cout && !(p.dbg & 4194304);
   int* const rowoff = reinterpret_cast<int*>(tl + WROWS * RS);
-  if constexpr (STAGES == 3 && kLdsT) __syncthreads();  // (every wave: `wide` may differ between the cout halves of a block)
+  if constexpr (STAGES >= 3 && kLdsT) __syncthreads();  // (every wave: `wide` may differ between the cout halves of a block)
 #pragma unroll
   for (int tc = 0; tc < TCN; ++tc) {
     const int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
@@ -1107,7 +1244,7 @@ __global__ void __launch_bounds__(256) conv_rowrun_kernel(const ConvArgs p, cons
 // kind-2 stems on split fp16 whose 128-pixel tiles stay inside output rows; FN2_CONV_DBG bit 65536 = off (A/B)
 template <typename OutT>
 static bool launch_rowrun(const ConvArgs& a, int tile, int phases, hipStream_t s) {
-  if ((a.dbg & 65536) || tile != 64 || phases != 1 || a.deconv || a.KW != 1 || a.KH_KW_hint < 1 || a.splitk != 1 || a.accum)
+  if ((a.dbg & 65536) || tile != 64 || phases != 1 || a.deconv || a.KW != 1 || a.KH_KW_hint < 1 || a.splitk != 1 || a.accum || a.wfrag)
     return false;
   if (a.OW % 128 != 0 || (a.in_cs != 8 && a.in_cs != 16)) return false;
   const int spp = a.in_cs / 4;
@@ -1153,11 +1290,12 @@ static bool launch_stem(const ConvArgs& a, int tile, int phases, hipStream_t s) 
 // stride-1 split-fp16 layers whose tiles stay inside image rows run the halo kernel; FN2_CONV_DBG bit 2048 = off (A/B)
 template <typename OutT>
 static bool launch_halo(const ConvArgs& a, int tile, int phases, hipStream_t s) {
-  if ((a.dbg & 2048) || a.stride != 1 || a.splitk != 1 || a.kg != 1 || !a.bp64 || (a.KW != 2 && a.KW != 3)) return false;
+  if ((a.dbg & 2048) || a.stride != 1 || a.splitk != 1 || a.kg != 1 || !a.bp64 || a.wfrag || (a.KW != 2 && a.KW != 3)) return false;
   if (a.deconv && (a.kh_ph[0] != a.KH || a.kh_ph[1] != a.KH || a.kw_ph[0] != a.KW || a.kw_ph[1] != a.KW)) return false;  // trimmed phases: conv_igemm2_kernel
   // one-round 128 x 64 grids (384..512 blocks) keep the 3-slot ring: two stages of DMA in flight beat the smaller
   // stream there (conv3_1 at batch 4: ring 0.196 ms per 3 launches, halo 0.213)
   if (tile == 128 && a.bp64 == 2 && !(a.dbg & 4096)) return false;
+  if (a.bp64 == 3) return false;  // deep ring chosen (conv.hip: build_args)
   const int bp = tile == 128 ? 64 : 128;
   if (a.OW % bp != 0 || a.M % bp != 0) return false;
   dim3 block(256);
@@ -1213,8 +1351,38 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
     else if (m16) hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, __VA_ARGS__, is_x2<T>::value>), grid, dim3(THREADS), 0, s, a); \
     else hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, __VA_ARGS__, false>), grid, dim3(THREADS), 0, s, a);            \
   } while (0)
-  if (tile == 128 && a.bp64 && a.kg == 3) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 768, 2, 2, 2, 1, 2, 3);
+  if (a.wfrag) {
+    if constexpr (is_x2<T>::value) {
+      if (tile == 64) {  // 64 couts x 128 pixels: two waves per 32-cout tile (each loads that tile's fragments), two pixel halves
+        dim3 grid(cdiv(a.M, 128), a.cout_pad / 64, z);
+        if (conv_name_sink().buf)
+          snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_igemm2_kernel<%s, %s, 2, 2, 1, 2, 2, 1, false, true, %s>",
+                   type_name<T>(), type_name<OutT>(), a.splitk > 1 ? "true" : "false");
+        else if (a.splitk > 1)
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 1, 2, 2, 1, false, true, true>), grid, dim3(256), 0, s, a);
+        else
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 2, 2, 1, 2, 2, 1, false, true, false>), grid, dim3(256), 0, s, a);
+      } else {
+        dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
+        const bool slab = a.splitk > 1;
+        if (conv_name_sink().buf)
+          snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_igemm2_kernel<%s, %s, 4, 1, 1, 2, %d, 1, false, true, %s>",
+                   type_name<T>(), type_name<OutT>(), a.wfrag == 2 ? 3 : 2, slab ? "true" : "false");
+        else if (a.wfrag == 2 && slab)
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 3, 1, false, true, true>), grid, dim3(256), 0, s, a);
+        else if (a.wfrag == 2)
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 3, 1, false, true, false>), grid, dim3(256), 0, s, a);
+        else if (slab)
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 2, 1, false, true, true>), grid, dim3(256), 0, s, a);
+        else
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 2, 1, false, true, false>), grid, dim3(256), 0, s, a);
+      }
+    } else {
+      return fail(FN2_ERR_UNSUPPORTED, "conv fast path: fragment-order weights are split fp16 only");
+    }
+  } else if (tile == 128 && a.bp64 && a.kg == 3) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 768, 2, 2, 2, 1, 2, 3);
   else if (tile == 128 && a.bp64 && a.kg == 2) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 512, 2, 2, 2, 1, 2, 2);
+  else if (tile == 128 && a.bp64 == 3) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 256, 2, 2, 2, 1, 6, 1);
   else if (tile == 128 && a.bp64 == 2) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 256, 2, 2, 2, 1, 3, 1);
   else if (tile == 128 && a.bp64) FN2_LAUNCH2(cdiv(a.M, 64), a.cout_pad / 128, 256, 2, 2, 2, 1, 2, 1);
   else if (tile == 128) FN2_LAUNCH2(cdiv(a.M, 128), a.cout_pad / 128, 256, 2, 2, 2, 2, 2, 1);

@@ -67,7 +67,7 @@ def _round_up(x, m):
 
 class Engine:
     def __init__(self, model, weights, batch, height, width, dtype="f32", device=None, heads_as_gemm=True,
-                 no_deconv_biases=None, strict=True, uint8_inputs=False, plain_stems=False):
+                 no_deconv_biases=None, strict=True, uint8_inputs=False, plain_stems=False, fragment_weights=None):
         """uint8_inputs: the plan starts with two table look-up passes that turn uint8 image bytes (set_inputs_u8) into
         the fp32 [0,1] images -- Net.adapt_x's `/ 255.0` (net.py:338-345) after the host-to-device copy instead of
         before it, byte-identical, a quarter of the bytes over the host link.
@@ -151,6 +151,11 @@ class Engine:
         # plain_stems (the trainer): FlowNetC's conv1 as the plain 7x7 stride-2 row-run convolution on the padded
         # 3-channel images instead of the space-to-depth form, so that its packed weight is the reference variable
         self.plain_stems = bool(plain_stems)
+        # fragment_weights: split-fp16 layers with more than 64 output channels whose launch would be the plain two-stage
+        # 128 x 64 instantiation keep their weights in MFMA-fragment order (wgt_layout 2) and run the kernel variant that
+        # loads them straight into registers (conv2.hip, WREG).  Not for the trainer (the filter-gradient kernels write
+        # layout 1).  None: FN2_WREG (default on).
+        self.fragment_weights = bool(int(os.environ.get("FN2_WREG", "1"))) if fragment_weights is None else bool(fragment_weights)
         self._head_t = None
         self.outputs = self._build()
         self._check_variables(strict)
@@ -251,8 +256,10 @@ class Engine:
         self.branch_of.append(self._branch)
 
     # ------------------------------------------------------------------ layers
-    def _conv(self, scope, spec, src, dst):
-        """src/dst: (buffer, c0, c).  One fn2_conv2d launch."""
+    def _conv(self, scope, spec, src, dst, up=None):
+        """src/dst: (buffer, c0, c).  One fn2_conv2d launch.  up (flow heads only): (name of the upsample_flowXtoY layer
+        that follows the head, its destination slice) -- returns True when that upsample was fused into the head's tail
+        launch (the caller then emits no fn2_upsample_flow for it)."""
         name, kind, k, stride, pad, cin, cout, act = spec
         sbuf, sc0, sc = src
         dbuf, dc0, dc = dst
@@ -262,8 +269,8 @@ class Engine:
         head_px = dbuf.shape[0] * dbuf.shape[1] * dbuf.shape[2]
         if (self.heads_as_gemm and kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1 and not act
                 and dbuf.dtype == torch.float32 and head_px >= int(os.environ.get("FN2_HEAD_GEMM_MIN", "8192"))
-                and self._head_gemm(scope, spec, src, dst)):
-            return
+                and self._head_gemm(scope, spec, src, dst, up)):
+            return up is not None and bool(int(os.environ.get("FN2_FUSE_UPFLOW", "1")))
         wname = f"{scope}/{name}/weights"
         in_code = self._code(sbuf)
         esz = 2 if in_code in (_hip.FN2_BF16, _hip.FN2_F16) else 4
@@ -301,6 +308,10 @@ class Engine:
         d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
         d.wgt_layout = layout
         d.out_scale = out_scale
+        if (self.fragment_weights and layout == 1 and tile >= int(os.environ.get("FN2_WREG_TILE_MIN", "128"))
+                and plan.wgt_dtype == _hip.FN2_F16X2 and self._wants_fragments(d)):
+            wdev = W.to_fragment_order(wdev)
+            d.wgt, d.wgt_layout, layout = wdev.data_ptr(), 2, 2
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
         self.desc_branch.append(self._branch)
@@ -310,7 +321,7 @@ class Engine:
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         if kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1:
             kern = f"flow_head_kernel<{tn}>"
-        elif layout == 1:
+        elif layout >= 1:
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
             m_px = dbuf.shape[0] * dbuf.shape[1] * dbuf.shape[2] // (4 if kind != "conv" else 1)
             kern = f"conv_igemm2_kernel<{tn}, {on}, {conv2_kernel_args(tile, m_px, cout_pad, 4 if kind != 'conv' else 1, tn == 'fn2::x2_t')}>"
@@ -326,9 +337,23 @@ class Engine:
         self.layer_io_bytes.append((f"{scope}/{name}", float(sbuf.shape[0] * sbuf.shape[1] * sbuf.shape[2] * cin * esz
                                                             + n * oh * ow * cout * osz + k * k * cin * cout * esz)))
 
-    def _head_gemm(self, scope, spec, src, dst):
+    def _wants_fragments(self, d):
+        """True when the library would run this layer on the plain two-stage 128 x 64 instantiation (no ring, K groups,
+        halo, 128 x 128 tiles): those are the launches the fragment-order variant replaces.  The split-K workspace is
+        not allocated yet at build time, so the question is asked with a stand-in workspace of the size the layer wants."""
+        need = int(self.lib.fn2_conv2d_workspace_bytes(C.byref(d)))
+        d.workspace, d.workspace_bytes = (1, need) if need else (None, 0)   # (never dereferenced: the name query launches nothing)
+        buf = C.create_string_buffer(256)
+        rc = self.lib.fn2_conv2d_kernel_name(C.byref(d), buf, 256)
+        d.workspace, d.workspace_bytes = None, 0
+        which = os.environ.get("FN2_WREG_KERNELS", "false>")
+        return rc == 0 and buf.value.decode().startswith("conv_igemm2_kernel") and buf.value.decode().endswith(which)
+
+    def _head_gemm(self, scope, spec, src, dst, up=None):
         """predict_flowN as a GEMM: 1x1 convolution with 18 outputs (tap*2 + co) on the LDS-DMA kernel into a shared
-        fp32 scratch tensor, then fn2_flow_head_gather.  Returns False when the input slice has no whole-line run."""
+        fp32 scratch tensor, then fn2_flow_head_tail: the nine shifted partials summed AND, in the same launch, the
+        upsample_flowXtoY that follows the head (up = (layer name, destination slice); flownet_s.py:54-63).  Returns
+        False when the input slice has no whole-line run."""
         name, kind, k, stride, pad, cin, cout, act = spec
         sbuf, sc0, sc = src
         pf = dst[0]
@@ -371,8 +396,20 @@ class Engine:
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
                  kernel=f"conv_igemm2_kernel<{tn}, float, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1, tn == 'fn2::x2_t')}>")
-        self._op(f"{scope}/{name}/gather", self.lib.fn2_flow_head_gather, _hip.ptr(head_t), 32,
-                 _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd)
+        if up is not None and int(os.environ.get("FN2_FUSE_UPFLOW", "1")):
+            up_name, (ubuf, uc0, uc) = up
+            uw = W.to_device(self._w(f"{scope}/{up_name}/weights"), torch.float32, self.device)  # [4,4,2,2] HW-O-I
+            ub = self._bias(scope, up_name, "deconv", 2)  # only the fusion net's two (flownet2.py:70-73, :86-89)
+            uv = self._v(ubuf, uc, uc0)
+            self.keep += [uw, ub, uv]
+            self.layers.append(dict(scope=scope, name=up_name, kind="upflow", src=pf, dst=up[1], w=uw, b=ub, view=uv))
+            self._op(f"{scope}/{name}/tail+{up_name}", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 32, 3,
+                     _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd, 0, _hip.ptr(uw),
+                     _hip.ptr(ub) if ub is not None else None, C.byref(uv), kernel="flow_head_tail")
+        else:
+            self._op(f"{scope}/{name}/tail", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 32, 3,
+                     _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd, 0, None, None, None,
+                     kernel="flow_head_tail")
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
         self.layer_io_bytes.append((f"{scope}/{name}", float(n * h * wd * (cin * esz + 2 * 4) + 18 * cin * esz)))
         return True
@@ -486,16 +523,20 @@ class Engine:
         h, w = c6_1.shape[1], c6_1.shape[2]
         pf = self._buf(f"{tag}/predict_flow6", N, h, w, 2, torch.float32)
         self._sync(Hd, M)  # conv6_1 is there
+        skips, decs = (512, 512, 256, 128), (512, 256, 128, 64)
         with self._lane(Hd):
-            self._conv(scope, L["predict_flow6"], (c6_1, 0, 1024), (pf, 0, 2))
+            # (a GEMM-form head takes the upsample_flow that follows it into its tail launch)
+            fused = self._conv(scope, L["predict_flow6"], (c6_1, 0, 1024), (pf, 0, 2),
+                               up=("upsample_flow6to5", (cats[5], skips[0] + decs[0], 2)))
         preds["predict_flow6"] = pf
         cur, cur_c = c6_1, 1024
-        for lvl, skip_c, dec_c in zip((5, 4, 3, 2), (512, 512, 256, 128), (512, 256, 128, 64)):
+        for i, (lvl, skip_c, dec_c) in enumerate(zip((5, 4, 3, 2), skips, decs)):
             cat = cats[lvl]
             h, w = cat.shape[1], cat.shape[2]
             self._conv(scope, L[f"deconv{lvl}"], (cur, 0, cur_c), (cat, skip_c, dec_c))
-            with self._lane(Hd):
-                self._upflow(scope, f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2))
+            if not fused:
+                with self._lane(Hd):
+                    self._upflow(scope, f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2))
             self._sync(M, Hd)  # concat complete for the main lane's readers (next deconv / interconv)
             if not interconv:
                 self._sync(Hd, M)  # ... and for the head (with an interconv the head waits for that instead)
@@ -507,8 +548,11 @@ class Engine:
                 self._sync(Hd, M)
                 head_src = (ic, 0, dec_c)
             pf = self._buf(f"{tag}/predict_flow{lvl}", N, h, w, 2, torch.float32)
+            up = None
+            if lvl > 2:
+                up = (f"upsample_flow{lvl}to{lvl - 1}", (cats[lvl - 1], skips[i + 1] + decs[i + 1], 2))
             with self._lane(Hd):
-                self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2))
+                fused = self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2), up=up)
             preds[f"predict_flow{lvl}"] = pf
         return preds
 
@@ -700,20 +744,24 @@ class Engine:
         M, Hd = self._branch, self._head_lane()
         self._sync(Hd, M)
         with self._lane(Hd):  # head + upsample beside the transposed conv, as in _refine
-            self._conv(scope, L["predict_flow2"], (f2_1, 0, 128), (pf2, 0, 2))
+            fused = self._conv(scope, L["predict_flow2"], (f2_1, 0, 128), (pf2, 0, 2),
+                               up=("fuse_upsample_flow2to1", (cat1, 160, 2)))
         self._conv(scope, L["fuse_deconv1"], (f2_1, 0, 128), (cat1, 128, 32))
-        with self._lane(Hd):
-            self._upflow(scope, "fuse_upsample_flow2to1", pf2, (cat1, 160, 2))
+        if not fused:
+            with self._lane(Hd):
+                self._upflow(scope, "fuse_upsample_flow2to1", pf2, (cat1, 160, 2))
         self._sync(M, Hd)
         ic1 = self._buf(f"{tag}/fuse_interconv1", N, H // 2, W_ // 2, 32)
         self._conv(scope, L["fuse_interconv1"], (cat1, 0, 162), (ic1, 0, 32))
         self._sync(Hd, M)
         pf1 = self._buf(f"{tag}/predict_flow1", N, H // 2, W_ // 2, 2, torch.float32)
         with self._lane(Hd):
-            self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2))
+            fused = self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2),
+                               up=("fuse_upsample_flow1to0", (cat0, 80, 2)))
         self._conv(scope, L["fuse_deconv0"], (cat1, 0, 162), (cat0, 64, 16))
-        with self._lane(Hd):
-            self._upflow(scope, "fuse_upsample_flow1to0", pf1, (cat0, 80, 2))
+        if not fused:
+            with self._lane(Hd):
+                self._upflow(scope, "fuse_upsample_flow1to0", pf1, (cat0, 80, 2))
         self._sync(M, Hd)
         ic0 = self._buf(f"{tag}/fuse_interconv0", N, H, W_, 16)
         self._conv(scope, L["fuse_interconv0"], (cat0, 0, 82), (ic0, 0, 16))
@@ -811,33 +859,78 @@ class Engine:
 
     def _launch_branches(self, main, extra):
         """Issue the plan with lane b > 0 on its own stream (inside a stream capture: parallel paths of the graph),
-        applying self.syncs; every lane is joined back into `main` at the end."""
+        applying self.syncs; every lane is joined back into `main` at the end.
+
+        The ORDER in which the launches are captured is the order in which a replay submits them (node creation order:
+        the runtime walks the graph's nodes on the host, a few microseconds each), so a lane whose launches all sit at the
+        end of the list -- FlowNetSD, built after the whole C -> S -> S chain -- would be submitted only after the ~100
+        launches in front of it.  FN2_LANE_ORDER: 'list' = the plan's own order; 'fair' (default) = the lanes merged so
+        that each has issued the same fraction of its launches; 'lanes' = side lanes first.  A sync (idx, waiter, waited)
+        keeps its meaning under any order: the event is recorded on `waited` when that lane has issued all its launches
+        in front of list position idx, and `waiter` waits for it before its first launch at or behind idx."""
         streams = dict(extra)
         streams[0] = main
         events = []  # kept alive until the capture has ended (an event destroyed while its record node is being captured
         #              is not something to rely on)
-
-        def wait(waiter, waited):
-            ev = torch.cuda.Event()
-            ev.record(streams[waited])
-            streams[waiter].wait_event(ev)
-            events.append(ev)
-
         self._capture_events = events
-        by_index = {}
-        for idx, waiter, waited in self.syncs:
-            by_index.setdefault(idx, []).append((waiter, waited))
-        for i, ((name, fn, args), br) in enumerate(zip(self.ops, self.branch_of)):
-            for waiter, waited in by_index.get(i, ()):
-                wait(waiter, waited)
-            rc = fn(*args, streams[br].cuda_stream)
+        mode = os.environ.get("FN2_LANE_ORDER", "fair")
+        n = len(self.ops)
+        lanes = sorted(set(self.branch_of) | {0})
+        per = {l: [i for i in range(n) if self.branch_of[i] == l] for l in lanes}
+        ptr = {l: 0 for l in lanes}
+        nxt = lambda l: per[l][ptr[l]] if ptr[l] < len(per[l]) else n   # list position of the lane's next launch
+        syncs = [dict(idx=idx, waiter=wr, waited=wd, ev=None) for idx, wr, wd in self.syncs]
+
+        def record_ready(lane):
+            """Lane `lane` has issued everything in front of nxt(lane): record the events of the syncs that wait for that."""
+            for sy in syncs:
+                if sy["waited"] == lane and sy["ev"] is None and sy["idx"] <= nxt(lane):
+                    ev = torch.cuda.Event()
+                    ev.record(streams[lane])
+                    events.append(ev)
+                    sy["ev"] = ev
+
+        for l in lanes:
+            record_ready(l)
+        issued = 0
+        self._issue_order = []
+        while issued < n:
+            # lanes whose next launch has all its events recorded
+            ready = []
+            for l in lanes:
+                i = nxt(l)
+                if i < n and all(sy["ev"] is not None for sy in syncs if sy["waiter"] == l and sy["idx"] <= i and not sy.get("done")):
+                    ready.append(l)
+            assert ready, "lane schedule deadlocked (syncs do not form a valid order)"
+            if mode == "list":
+                l = min(ready, key=nxt)
+            elif mode == "lanes":
+                l = max(ready)
+            else:
+                l = min(ready, key=lambda q: (ptr[q] / max(len(per[q]), 1), nxt(q)))
+            i = nxt(l)
+            for sy in syncs:
+                if sy["waiter"] == l and sy["idx"] <= i and not sy.get("done"):
+                    streams[l].wait_event(sy["ev"])
+                    sy["done"] = True
+            name, fn, args = self.ops[i]
+            rc = fn(*args, streams[l].cuda_stream)
             if rc:
                 try:
                     _hip.check(rc)
                 except Exception as e:
                     raise type(e)("%s: %s" % (name, e)) from None
+            self._issue_order.append(i)
+            ptr[l] += 1
+            issued += 1
+            record_ready(l)
+        for sy in syncs:  # waits behind a lane's last launch (nothing left to order: the final join covers them)
+            sy["done"] = True
         for b in extra:
-            wait(0, b)
+            ev = torch.cuda.Event()
+            ev.record(streams[b])
+            main.wait_event(ev)
+            events.append(ev)
 
     def __call__(self, input_a, input_b):
         self.set_inputs(input_a, input_b)

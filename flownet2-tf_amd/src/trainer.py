@@ -112,7 +112,8 @@ class FlowNetSTrainer:
             self.loss_terms, self.gt_scale = {"predict_flow0": 1.0}, 1.0
             if self.hfem:
                 raise ValueError("hard-flow-example mining belongs to FlowNetS_interp")
-        self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False, plain_stems=True)
+        self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False, plain_stems=True,
+                          fragment_weights=False)  # (the filter-gradient kernels write the row-major packed layout)
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
         self.schedule, self.eps = schedule, eps

@@ -225,6 +225,21 @@ def join_f16x2(split):
 _TORCH_OF_CODE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
 
 
+def to_fragment_order(wdev):
+    """Split-fp16 packed weight on the device, layout 1 ([..., cout_pad, k] rows of 128-byte stages
+    [hi g0 | lo g0 | ... | hi g3 | lo g3]) -> wgt_layout 2 of fn2_conv2d: per 32-row tile and stage four 1 KiB blocks
+    f = 2 q + part (q = which pair of 8-channel groups, part = hi / lo), each lane-linear: lane 32 h + r holds the
+    16-byte chunk 4 q + 2 h + part of row r -- exactly the MFMA A-operand fragment the kernel's wave loads with one
+    16-byte-per-lane instruction.  A pure permutation of 16-byte chunks (same size, same values)."""
+    assert wdev.dtype == torch.float16 and wdev.shape[-2] % 32 == 0 and (wdev.shape[-1] * 2) % 128 == 0
+    lead = tuple(wdev.shape[:-2])
+    ct, st = wdev.shape[-2] // 32, wdev.shape[-1] * 2 // 128
+    v = wdev.contiguous().view(torch.uint8).reshape(lead + (ct, 32, st, 2, 2, 2, 16))   # [.., ct, r, st, q, h, part, 16 B]
+    n = len(lead)
+    perm = tuple(range(n)) + (n, n + 2, n + 3, n + 5, n + 4, n + 1, n + 6)            # [.., ct, st, q, part, h, r, 16 B]
+    return v.permute(perm).contiguous().view(torch.float16).reshape(wdev.shape)
+
+
 def packed_to_device(packed, wgt_code, device):
     """Packed fp32 weight -> device tensor of the element type the kernel plan asks for."""
     if wgt_code == 3:

@@ -202,6 +202,21 @@ int fn2_conv2d_kernel_name(const fn2_conv_desc* desc, char* name, int cap);
  * 1x1 convolution with 18 outputs t[pix][tap*2+co] (weight w1x1[ci][tap*2+co] = w[ky][kx][ci][co]) into an fp32
  * scratch tensor, then this call: out[n,y,x,co] = bias[co] + sum_taps t[n,y+ky-1,x+kx-1][tap*2+co].  out dense [n,h,w,2]. */
 int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out, int n, int h, int w, void* stream);
+/* The tail of a flow head in one launch: fn2_flow_head_gather generalised to taps x taps (3 or 5) shifted partials
+ *   pf[n,y,x,co] = bias[co] + sum_{ky,kx < taps} t[n, y+ky-taps/2, x+kx-taps/2][(ky*taps+kx)*2 + co]   (zero outside),
+ * written dense fp32 [n,h,w,2], followed -- when up_w is not NULL -- by upsample_flowXtoY on it (fn2_upsample_flow:
+ * flownet_s.py:60-63; up_bias NULL except in the fusion net, flownet2.py:70-73, :86-89) into the [n,2h,2w,2] view up_out.
+ * taps = 5 serves a COMPOSED head: where the reference applies a linear 3x3 interconvN and then the linear 3x3
+ * predict_flowN to it (flownet_sd.py:60-64 ..., flownet2.py:74-77, :90-93; activation_fn=None on both), the two are
+ * one 5x5 convolution of the concat buffer with weights w5[u] = sum_{t+s=u} w2[t] w1[s], except on the image's outermost
+ * pixel ring (the reference zero-pads the interconv OUTPUT): ring != 0 says those pixels were already written to pf by
+ * fn2_flow_head_ring and must be taken from there. */
+int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, float* pf, int n, int h, int w, int ring,
+                       const float* up_w, const float* up_bias, const fn2_tensor* up_out, void* stream);
+/* Border ring of a composed head: pf[n,y,x,o] = bc[case][o] + sum_{u in 5x5} sum_ci wc[case][u][ci][o] x[n, y+uy-2, x+ux-2, ci]
+ * for the pixels with y in {0, h-1} or x in {0, w-1}; case = 3*cy + cx with c = 0 / 1 / 2 for the low border / interior /
+ * high border of that axis.  x: split-fp16 view; wc: fp32 [9][25][8*ceil(c/8)][2], zero on the pad channels; bc: fp32 [9][2]. */
+int fn2_flow_head_ring(const fn2_tensor* x, const float* wc, const float* bc, float* pf, void* stream);
 /* upsample_flowXtoY: 2->2 channel conv-transpose 4x4 s2 crop 1, linear (flownet_s.py:60-63).
  * in: fp32 [n,h,w,2] dense; w: fp32 [4][4][2 out][2 in] (reference HW-O-I layout); out: view with c=2.
  * bias: fp32 [2] or NULL.  NULL inside the refinement scopes of S / C / SD (biases_initializer=None, flownet_s.py:53,

@@ -35,7 +35,7 @@ def _from_dev(t, code):
 
 
 def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0, cout_off=0, extra_out=0,
-             use_ws=True, force_generic=False, in_f32=False, act_grad=None):
+             use_ws=True, force_generic=False, in_f32=False, act_grad=None, fragments=False):
     """Drive the C ABI directly.  x: [N,H,W,Cin] fp32.  Returns fp32 numpy [N,oh,ow,Cout].
     in_f32: fp32 input into a non-fp32 engine format (the stem of a split-fp16 network)."""
     from src import _hip, weights as W
@@ -70,6 +70,8 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
         k2 = int(np.floor(np.log2(1024.0 / np.abs(packed).max())))
         packed, out_scale = packed * 2.0 ** k2, 2.0 ** -k2
     wdev = W.packed_to_device(packed, plan.wgt_dtype, "cuda")
+    if fragments:  # wgt_layout 2: the packed matrix re-tiled into MFMA-fragment order (weights straight to registers)
+        wdev = W.to_fragment_order(wdev)
     bdev = torch.from_numpy(b).cuda() if b is not None else None
     d = _hip.Fn2ConvDesc()
     d.inp = _hip.view(xin, cin, cin_off, in_code)
@@ -81,7 +83,7 @@ def run_conv(x, w, b, kind, k, stride, pad, act, dtype, out_f32=False, cin_off=0
     d.stride, d.pad = stride, pad
     d.act = 1 if act else 0
     d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
-    d.wgt_layout = plan.layout
+    d.wgt_layout = 2 if fragments else plan.layout
     d.out_scale = out_scale
     if act_grad is not None:  # (y [N,oh,ow,Cout] fp32, c0, c1): out += result, then the LeakyReLU factor from y on [c0, c1)
         ynp, d.act_grad_c0, d.act_grad_c1 = act_grad
@@ -457,3 +459,88 @@ def test_flow_head_gather_small_and_tiled(N, H, W):
     _hip.check(lib.fn2_flow_head_gather(td.data_ptr(), 32, bd.data_ptr(), out.data_ptr(), N, H, W, _hip.stream_ptr()))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("taps", [3, 5])
+@pytest.mark.parametrize("N,H,W", [(2, 384, 512), (4, 48, 64), (3, 6, 8), (2, 13, 37)])
+@pytest.mark.parametrize("up_dtype", [None, "f16x2", "f32"])
+def test_flow_head_tail(taps, N, H, W, up_dtype):
+    """fn2_flow_head_tail: pf = bias + the taps x taps shifted partials (zero outside the image), then -- same launch --
+    upsample_flowXtoY of it (4x4 stride-2 transposed conv, flownet_s.py:60-63; with a bias as in the fusion net,
+    flownet2.py:70-73) into a 2-channel slice.  Both tile forms (8-row tiles from 256 tiles up, 4 x 32 below), ragged
+    edges, and `ring`: the outermost pixel ring is taken from pf as it was, not gathered."""
+    from src import _hip, weights as Wt
+    lib = _hip.lib()
+    rng = np.random.default_rng(N * 1000 + H + taps)
+    cs = 64 if taps == 5 else 32
+    t = rng.standard_normal((N, H, W, cs)).astype(np.float32)
+    bias = np.array([0.25, -1.5], np.float32)
+    r = taps // 2
+    want = np.zeros((N, H, W, 2), np.float32) + bias
+    tp = np.pad(t, ((0, 0), (r, r), (r, r), (0, 0)))
+    for ky in range(taps):          # fp32 accumulation in the kernel's order
+        for kx in range(taps):
+            j = (ky * taps + kx) * 2
+            want = want + tp[:, ky:ky + H, kx:kx + W, j:j + 2]
+    for ring in (0, 1):
+        pf0 = rng.standard_normal((N, H, W, 2)).astype(np.float32)
+        exp = want.copy()
+        if ring:  # the border ring keeps what pf held
+            m = np.zeros((H, W), bool)
+            m[0], m[-1], m[:, 0], m[:, -1] = True, True, True, True
+            exp[:, m] = pf0[:, m]
+        td, bd = torch.from_numpy(t).cuda(), torch.from_numpy(bias).cuda()
+        pf = torch.from_numpy(pf0).cuda()
+        if up_dtype is None:
+            _hip.check(lib.fn2_flow_head_tail(td.data_ptr(), cs, taps, bd.data_ptr(), pf.data_ptr(), N, H, W, ring,
+                                              None, None, None, _hip.stream_ptr()))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(pf.cpu().numpy(), exp)
+            continue
+        uw = rnd((4, 4, 2, 2), 8, 0.5)
+        ub = np.array([0.375, -1.25], np.float32)
+        code = _CODE[up_dtype]
+        out = _to_dev(np.full((N, 2 * H, 2 * W, 16), 3.0, np.float32), up_dtype)
+        v = _hip.view(out, 2, 10, code)
+        uwd, ubd = torch.from_numpy(uw).cuda(), torch.from_numpy(ub).cuda()
+        _hip.check(lib.fn2_flow_head_tail(td.data_ptr(), cs, taps, bd.data_ptr(), pf.data_ptr(), N, H, W, ring,
+                                          uwd.data_ptr(), ubd.data_ptr(), C.byref(v), _hip.stream_ptr()))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(pf.cpu().numpy(), exp)
+        res = _from_dev(out, code)
+        np.testing.assert_allclose(res[..., 10:12], refnn.conv2d_transpose(exp, uw, bias=ub), rtol=1e-5, atol=1e-5)
+        assert np.all(res[..., :10] == 3.0) and np.all(res[..., 12:] == 3.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("kind,k,s,p,cin,cout,N,H,W", [
+    ("conv", 5, 2, 2, 64, 128, 2, 48, 64),      # conv2: 5x5 stride 2 (flownet_s.py:40)
+    ("conv", 3, 1, 1, 256, 256, 2, 24, 32),     # conv3_1
+    ("conv", 3, 2, 1, 256, 512, 1, 24, 32),     # conv4: split-K at this size (slabs + finalize)
+    ("conv", 3, 1, 1, 473, 200, 1, 13, 19),     # ragged pixels, couts past the view's end, odd stage count, Cin 473
+    ("conv", 1, 1, 0, 96, 130, 3, 9, 7),        # 1x1, three stages, second cout tile almost empty
+    ("deconv", 4, 2, 1, 386, 128, 2, 12, 16),   # four phases (flownet_s.py:89 deconv2 has 64; 128 takes the 128-cout tile)
+    ("deconv", 4, 2, 1, 770, 160, 1, 6, 8),     # phases + split-K
+    ("conv", 3, 2, 1, 64, 64, 2, 48, 64),       # 64-cout tile (two waves per 32-cout tile): FlowNetSD conv1 (flownet_sd.py:30)
+    ("deconv", 4, 2, 1, 386, 64, 2, 12, 16),    # deconv2 (flownet_s.py:89)
+    ("conv", 3, 1, 1, 162, 40, 1, 9, 21),       # 64-cout tile, ragged everything
+])
+def test_conv_fragment_order_weights(kind, k, s, p, cin, cout, N, H, W, out_f32):
+    """wgt_layout 2 (conv2.hip, WREG): the weight operand in MFMA-fragment order, loaded straight into registers by the
+    wave that owns the 32 couts; pixel rows through LDS-DMA.  Same arithmetic as layout 1: compared with the oracle and
+    with the layout-1 launch (another tile / split choice: fp32 summation order only)."""
+    x = rnd((N, H, W, cin), 70)
+    if kind == "conv":
+        w = rnd((k, k, cin, cout), 71, (2.0 / (k * k * cin)) ** 0.5)
+        b = rnd((cout,), 72, 0.1)
+        want = refnn.conv2d(x, w, b, stride=s, padding=p, activation=refnn.leaky_relu)
+    else:
+        w = rnd((4, 4, cout, cin), 71, (2.0 / (4 * cin)) ** 0.5)
+        b = None
+        want = refnn.conv2d_transpose(x, w, activation=refnn.leaky_relu)
+    got = run_conv(x, w, b, kind, k, s, p, True, "f16x2", out_f32=out_f32, cout_off=8, extra_out=8, fragments=True)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+    base = run_conv(x, w, b, kind, k, s, p, True, "f16x2", out_f32=out_f32, cout_off=8, extra_out=8)
+    np.testing.assert_allclose(got, base, rtol=1e-5, atol=1e-5)
