@@ -42,7 +42,10 @@ constexpr int C3_XS = FN2_C3_XS;  // 32-pixel column spans per block (waves per 
 constexpr int C3_HALF = C3_XS == 2 ? 64 : 48;  // LDS rows per column parity: window half-indices (16 (XS-1) + 36 needed, 3 tiles of 16 read per span)
 constexpr int C3_ROWS = 2 * C3_HALF;
 constexpr int C3_OTS = 168;    // channels of a chunk of 8 displacement rows
-constexpr int C3_SLOTS = 3;
+#ifndef FN2_C3_SLOTS
+#define FN2_C3_SLOTS 3
+#endif
+constexpr int C3_SLOTS = FN2_C3_SLOTS;   // ring slots; C3_SLOTS - 1 stages of DMA in flight
 constexpr int C3_SG = 1;       // 128-byte channel lines per stage
 constexpr int C3_TY = 2;       // same-parity A rows per block
 constexpr int C3_NW = 2 * C3_TY * C3_XS;  // waves per block: rows x column parities x spans
@@ -163,17 +166,17 @@ __global__ void __launch_bounds__(64 * C3_NW) corr3_kernel(const CorrArgs p, con
   for (int tb = 0; tb < 3; ++tb) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (S > 0) {
-    issue_stage();
-    issue_stage();
+#pragma unroll
+    for (int d = 0; d < C3_SLOTS - 1; ++d) issue_stage();
     __syncthreads();  // the zeroed output tile is visible to every wave (DMA still in flight: waited below)
     int cslot = 0;
     for (int kk = 0; kk < nrow; ++kk) {
 #pragma unroll
       for (int st = 0; st < NST; ++st) {  // static st: fa[] indices are compile-time
         // all but the newest stage (PPW pieces of this wave) have landed; every wave is done reading slot (s-1)%3
-        if constexpr (PPW == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        else if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+        // (all but the C3_SLOTS - 2 newest stages of this wave's pieces)
+        static_assert(PPW * (C3_SLOTS - 2) <= 63, "vmcnt field");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(PPW * (C3_SLOTS - 2)) : "memory");
         issue_stage();
         uint4 (*slot)[C3_ROWS * 8] = ring[cslot];
         cslot = cslot == C3_SLOTS - 1 ? 0 : cslot + 1;

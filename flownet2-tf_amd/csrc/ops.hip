@@ -347,7 +347,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ void __launch_bounds__(256) downsample_kernel(const float* __restrict__ in,
                                                          float* __restrict__ out, int N, int Hin, int Win,
                                                          int C, int oh, int ow, float wscale, float hscale,
-                                                         int wr, int hr) {
+                                                         int wr, int hr, float in_scale) {
   const int lane = threadIdx.x & 63;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) downsample_kernel(const float* __restrict
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             if (c0 + c < C) {
-              const float s = p[c];
+              const float s = p[c] * in_scale;
               if (s != s) {  // NaN sample: counts as NaN weight only, :59-63
                 an[c] += wgt;
               } else {
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256) downsample_kernel(const float* __restrict
 // Block per output row (n, dy), a thread per (window row, dx, c) walks its few taps.
 __global__ void __launch_bounds__(256) downsample_sep_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              int N, int Hin, int Win, int C, int oh, int ow,
-                                                             float wscale, float hscale, int wr, int hr) {
+                                                             float wscale, float hscale, int wr, int hr, float in_scale) {
   extern __shared__ float rows[];  // [wh][ow*C][3]
   const int dy = blockIdx.x % oh, n = blockIdx.x / oh;
   const float srcy = ((float)dy / (float)(oh - 1)) * (float)(Hin - 1);
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) downsample_sep_kernel(const float* __rest
           const int xo = ix - wr + k;
           if (xo < 0 || xo >= Win) continue;
           const float wgt = fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale);
-          const float2 sv = p[xo];
+          const float2 sv = make_float2(p[xo].x * in_scale, p[xo].y * in_scale);
           if (sv.x != sv.x) an0 += wgt; else { av0 += sv.x * wgt; aw0 += wgt; }
           if (sv.y != sv.y) an1 += wgt; else { av1 += sv.y * wgt; aw1 += wgt; }
         }
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(256) downsample_sep_kernel(const float* __rest
         const int xo = ix - wr + k;
         if (xo < 0 || xo >= Win) continue;
         const float wgt = fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale);
-        const float sv = p[(long)xo * C];
+        const float sv = p[(long)xo * C] * in_scale;
         if (sv != sv) an += wgt; else { av += sv * wgt; aw += wgt; }
       }
     }
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256) downsample_sep_kernel(const float* __rest
 // C <= 4 channels per tap, shuffle reduction, vertical weights applied per row, then one LDS reduction over rows.
 __global__ void __launch_bounds__(1024) downsample_wide_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                int N, int Hin, int Win, int C, int oh, int ow,
-                                                               float wscale, float hscale, int wr, int hr) {
+                                                               float wscale, float hscale, int wr, int hr, float in_scale) {
   __shared__ float part[16][4][3];
   const int dx = blockIdx.x % ow, dy = (blockIdx.x / ow) % oh, n = blockIdx.x / ow / oh;
   const float srcx = ((float)dx / (float)(ow - 1)) * (float)(Win - 1);
@@ -488,7 +488,8 @@ __global__ void __launch_bounds__(1024) downsample_wide_kernel(const float* __re
       if (xo < 0 || xo >= Win) continue;
       const float wgt = wy * fmaxf(0.f, 1.f - fabsf((float)xo - srcx) / wscale);
       if (C == 2) {  // both channels of a tap as one 8-byte load
-        const float2 sv = reinterpret_cast<const float2*>(p)[xo];
+        const float2 raw = reinterpret_cast<const float2*>(p)[xo];
+        const float2 sv = make_float2(raw.x * in_scale, raw.y * in_scale);
         if (sv.x != sv.x) an[0] += wgt; else { av[0] += sv.x * wgt; aw[0] += wgt; }
         if (sv.y != sv.y) an[1] += wgt; else { av[1] += sv.y * wgt; aw[1] += wgt; }
         continue;
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(1024) downsample_wide_kernel(const float* __re
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (c < C) {
-          const float sv = p[(long)xo * C + c];
+          const float sv = p[(long)xo * C + c] * in_scale;
           if (sv != sv) an[c] += wgt; else { av[c] += sv * wgt; aw[c] += wgt; }
         }
     }
@@ -693,6 +694,11 @@ int fn2_flow_warp_grad_f32(const float* image, const float* flow, const float* g
 
 int fn2_downsample_f32(const float* in, float* out, int n, int in_h, int in_w, int c, int out_h, int out_w,
                        void* stream) {
+  return fn2_downsample_scaled_f32(in, 1.0f, out, n, in_h, in_w, c, out_h, out_w, stream);  // (x * 1.0f == x, NaN included)
+}
+
+int fn2_downsample_scaled_f32(const float* in, float in_scale, float* out, int n, int in_h, int in_w, int c, int out_h,
+                              int out_w, void* stream) {
   FN2_REQUIRE(in && out, "downsample: null pointer");
   FN2_REQUIRE(n >= 1 && in_h >= 1 && in_w >= 1 && c >= 1, "Input images must have rank 4");  // downsample_kernel.cc:25
   FN2_REQUIRE(out_h >= 1 && out_w >= 1, "downsample: size must be positive");
@@ -704,13 +710,13 @@ int fn2_downsample_f32(const float* in, float* out, int n, int in_h, int in_w, i
   const size_t lds = (size_t)(2 * hr + 1) * out_w * c * 3 * sizeof(float);
   if (2 * wr + 1 >= 32 && c <= 4 && nout < (1L << 30))
     hipLaunchKernelGGL(downsample_wide_kernel, dim3((unsigned)nout), dim3(1024), 0, (hipStream_t)stream, in, out, n, in_h,
-                       in_w, c, out_h, out_w, wscale, hscale, wr, hr);
+                       in_w, c, out_h, out_w, wscale, hscale, wr, hr, in_scale);
   else if (lds <= 64 * 1024 && (long)n * out_h < (1L << 30))
     hipLaunchKernelGGL(downsample_sep_kernel, dim3(n * out_h), dim3(256), lds, (hipStream_t)stream, in, out, n,
-                       in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr);
+                       in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr, in_scale);
   else
     hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(nout * 64, 256)), dim3(256), 0, (hipStream_t)stream, in,
-                       out, n, in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr);
+                       out, n, in_h, in_w, c, out_h, out_w, wscale, hscale, wr, hr, in_scale);
   FN2_CHECK_LAUNCH("downsample");
   return FN2_OK;
 }

@@ -233,6 +233,29 @@ __global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict_
 
 // dst[i] = map[i] >= 0 ? src[map[i]] : 0  -- derives the transposed / phase-decomposed weights that the
 // input-gradient convolutions read from the master (forward-layout) weights once per step.
+// dst += src (fp32, n % 4 == 0 elements as 16-byte accesses; the tail scalar)
+__global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 d = reinterpret_cast<float4*>(dst)[i];
+    const float4 a = reinterpret_cast<const float4*>(src)[i];
+    d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+    reinterpret_cast<float4*>(dst)[i] = d;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] += src[(n4 << 2) + threadIdx.x];
+}
+
+// dst[pix][0..c) = src[pix][c0..c0+c) of an fp32 NHWC buffer with channel stride cs (dense destination)
+__global__ void __launch_bounds__(256) slice_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long npix,
+                                                         int c, int cs, int c0) {
+  const long total = npix * c;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c;
+    const int ch = (int)(i - pix * c);
+    dst[i] = src[pix * cs + c0 + ch];
+  }
+}
+
 __global__ void __launch_bounds__(256) gather_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                      const int* __restrict__ map, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -1117,6 +1140,31 @@ int fn2_to_f16x2(void* dst, const float* src, const int32_t* map, int64_t n, flo
   hipLaunchKernelGGL(to_x2_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, map, (x2_t*)dst,
                      (long)(n / 8), scale);
   FN2_CHECK_LAUNCH("to_f16x2");
+  return FN2_OK;
+}
+
+int fn2_fill_zero(void* dst, int64_t bytes, void* stream) {
+  FN2_REQUIRE(dst && bytes >= 0, "fill_zero: bad arguments");
+  if (bytes == 0) return FN2_OK;
+  FN2_HIP(hipMemsetAsync(dst, 0, (size_t)bytes, (hipStream_t)stream));
+  return FN2_OK;
+}
+
+int fn2_add_f32(float* dst, const float* src, int64_t n, void* stream) {
+  FN2_REQUIRE(dst && src && n >= 0, "add: bad arguments");
+  if (n == 0) return FN2_OK;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, (long)n);
+  FN2_CHECK_LAUNCH("add");
+  return FN2_OK;
+}
+
+int fn2_slice_copy_f32(const fn2_tensor* src, float* dst, void* stream) {
+  FN2_REQUIRE(src && src->data && dst && src->dtype == FN2_F32, "slice_copy: fp32 source view");
+  FN2_REQUIRE(src->c >= 1 && src->c0 >= 0 && src->c0 + src->c <= src->cs, "slice_copy: channel slice outside the buffer");
+  const long npix = (long)src->n * src->h * src->w;
+  hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(npix * src->c, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)src->data, dst, npix, src->c, src->cs, src->c0);
+  FN2_CHECK_LAUNCH("slice_copy");
   return FN2_OK;
 }
 

@@ -60,6 +60,10 @@ PROTOTYPES = {
     "fn2_flow_warp_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fn2_flow_warp_grad_f32": (_i, [_p] * 5 + [_i] * 4 + [_p]),
     "fn2_downsample_f32": (_i, [_p, _p] + [_i] * 6 + [_p]),
+    "fn2_downsample_scaled_f32": (_i, [_p, _f, _p] + [_i] * 6 + [_p]),
+    "fn2_fill_zero": (_i, [_p, C.c_int64, _p]),
+    "fn2_add_f32": (_i, [_p, _p, C.c_int64, _p]),
+    "fn2_slice_copy_f32": (_i, [_tp, _p, _p]),
     "fn2_resize_bilinear_f32": (_i, [_p, _p] + [_i] * 6 + [_f, _p]),
     "fn2_conv2d_plan": (_i, [_i, _i, _i, C.POINTER(Fn2ConvPlan)]),
     "fn2_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(Fn2ConvDesc)]),

@@ -1,19 +1,46 @@
 """Training losses of the reference (FlowNetS.loss, src/flownet_s/flownet_s.py:122-161;
 average_endpoint_error, src/utils.py:209-224; FlowNet2.loss, src/flownet2/flownet2.py:107-116).
-The NaN-aware ground-truth downsample is the HIP op; the scalar reductions are torch device ops."""
+The NaN-aware ground-truth downsample (with the label scaling inside it) and the endpoint-error reductions are
+calls into libflownet2_hip.so (fn2_downsample_scaled_f32, fn2_epe_loss_grad); only the top-k selection of the
+'hard' mining mode of FlowNetS_interp's loss is a torch device op."""
 import numpy as np
 import torch
 
+from . import _hip
 from .downsample import downsample
 
 LOSS_WEIGHTS = (0.32, 0.08, 0.02, 0.01, 0.005)
 
 
+def _dev32(x, like=None):
+    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+    return t.to(device=_hip.require_device() if like is None else like.device, dtype=torch.float32).contiguous()
+
+
 def average_endpoint_error(labels, predictions):
-    """sum over pixels of ||pred - label||_2, divided by the batch size only."""
-    n = predictions.shape[0]
-    d = predictions.float() - labels.float()
-    return torch.sqrt((d * d).sum(dim=3)).sum() / n
+    """sum over pixels of ||pred - label||_2, divided by the batch size only (utils.py:209-224): fn2_epe_loss_grad's
+    loss output (its gradient output goes to a scratch tensor)."""
+    pred = _dev32(predictions)
+    lab = _dev32(labels, pred)
+    if lab.shape != pred.shape or pred.ndim != 4 or pred.shape[3] != 2:
+        raise ValueError("average_endpoint_error: labels and predictions must both be [N, H, W, 2]")
+    n, h, w, _ = pred.shape
+    lib, s = _hip.lib(), _hip.stream_ptr()
+    scratch = torch.empty_like(pred)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    _hip.check(lib.fn2_fill_zero(_hip.ptr(loss), 4, s))
+    _hip.check(lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(lab), _hip.ptr(scratch), _hip.ptr(loss), n, h, w, 1.0, 1.0, s))
+    return loss[0]
+
+
+def scaled_downsample(flow, scale, size):
+    """downsample(scale * flow, size) in one pass (flownet_s.py:123-129): fn2_downsample_scaled_f32."""
+    x = _dev32(flow)
+    n, h, w, c = x.shape
+    out = torch.empty((n, int(size[0]), int(size[1]), c), dtype=torch.float32, device=x.device)
+    _hip.check(_hip.lib().fn2_downsample_scaled_f32(_hip.ptr(x), float(scale), _hip.ptr(out), n, h, w, c, int(size[0]),
+                                                    int(size[1]), _hip.stream_ptr()))
+    return out
 
 
 def average_endpoint_error_hfem(labels, predictions, add_hfem='', lambda_w=2., perc_hfem=50, edges=None):
@@ -34,8 +61,9 @@ def average_endpoint_error_hfem(labels, predictions, add_hfem='', lambda_w=2., p
 
 
 def mean_endpoint_error(gt_flow, pred_flow):
-    """Mean over every pixel of the batch of ||gt - pred||_2 (src/utils.py:342-351)."""
-    return torch.linalg.vector_norm(gt_flow.float() - pred_flow.float(), dim=-1).mean()
+    """Mean over every pixel of the batch of ||gt - pred||_2 (src/utils.py:342-351) = average_endpoint_error / (H W)."""
+    pred = _dev32(pred_flow)
+    return average_endpoint_error(gt_flow, pred) / float(pred.shape[1] * pred.shape[2])
 
 
 def multiscale_hfem_loss(targets, predictions, add_hard_flow_mining='', lambda_weight=2., hard_examples_perc=50,
@@ -69,11 +97,11 @@ def _as_dev(x, like):
 
 def multiscale_loss(flow, predictions, weights=None, scope=None, l2=4e-4, gt_scale=0.05):
     p6 = predictions['predict_flow6']
-    flow = _as_dev(flow, p6).to(device=p6.device, dtype=torch.float32) * gt_scale
+    flow = _dev32(flow, p6)
     losses = []
     for lvl in (6, 5, 4, 3, 2):
         p = predictions['predict_flow%d' % lvl]
-        losses.append(average_endpoint_error(downsample(flow, [p.shape[1], p.shape[2]]), p))
+        losses.append(average_endpoint_error(scaled_downsample(flow, gt_scale, [p.shape[1], p.shape[2]]), p))
     # tf.losses.compute_weighted_loss(list, weights) with SUM_BY_NONZERO_WEIGHTS: (sum w_i L_i) / 5
     total = sum(w * l for w, l in zip(LOSS_WEIGHTS, losses)) / 5.0
     if weights is not None and scope is not None:

@@ -546,14 +546,15 @@ class FlowNetSTrainer:
         da, db = torch.empty_like(a), torch.empty_like(b)
         self.keep += [vy, vg, gd, da, db]
 
+        vslice = _hip.view(gnet, c, c0, F32)
+        self.keep.append(vslice)
+
         def copy_grad(s):
-            gd.copy_(gnet[..., c0:c0 + c])
-            return 0
+            return self.lib.fn2_slice_copy_f32(C.byref(vslice), _hip.ptr(gd), s)
 
         def add_grads(s):
-            ga.add_(da)
-            gb.add_(db)
-            return 0
+            return (self.lib.fn2_add_f32(_hip.ptr(ga), _hip.ptr(da), ga.numel(), s)
+                    or self.lib.fn2_add_f32(_hip.ptr(gb), _hip.ptr(db), gb.numel(), s))
         add_grads.writes = [(t.data_ptr(), t.data_ptr() + 4 * t.numel(), 0, t.shape[3]) for t in (ga, gb)]
 
         ops = [(self.lib.fn2_leaky_bwd, (C.byref(vy), C.byref(vg), None)),
@@ -643,14 +644,9 @@ class FlowNetSTrainer:
         eng, s = self.eng, _hip.stream_ptr()
         self.gt.copy_(torch.as_tensor(gt_flow).to(dtype=torch.float32), non_blocking=True)
         eng.set_inputs(input_a, input_b)
-        self.grad_arena.zero_()
-        for g in self.gbufs.values():
-            if g.data_ptr() not in self._no_zero:
-                g.zero_()
-        self.loss_dev.zero_()
+        self._zero_buffers(s)
         eng.launch()
         # ---- loss and its gradient at the five scales (flownet_s.py:122-158)
-        gts = self.gt * self.gt_scale
         edges_dev = None
         if edges is not None:
             edges_dev = (edges if isinstance(edges, torch.Tensor) else torch.as_tensor(np.asarray(edges))).to(
@@ -661,7 +657,9 @@ class FlowNetSTrainer:
             pred = eng.outputs[pname]
             n, h, w, _ = pred.shape
             label = torch.empty_like(pred)
-            _hip.check(self.lib.fn2_downsample_f32(_hip.ptr(gts), _hip.ptr(label), n, self.H, self.W, 2, h, w, s))
+            # labels: downsample(gt_scale * gt) -- the scaling (flownet_s.py:123) happens per sample inside the op
+            _hip.check(self.lib.fn2_downsample_scaled_f32(_hip.ptr(self.gt), self.gt_scale, _hip.ptr(label), n, self.H, self.W,
+                                                          2, h, w, s))
             pw = self._pixel_weights(pred, label, edges_dev) if self.hfem else None
             if pw is None:
                 _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
@@ -688,6 +686,16 @@ class FlowNetSTrainer:
                     self._pending.append(h)
                 nb += 1
         return self.loss_dev
+
+    def _zero_buffers(self, s):
+        """Zero what the step accumulates into: the flat parameter-gradient arena, the activation-gradient buffers whose
+        first writer adds (the others are stored into, _plan_zeroing) and the loss scalar -- memset nodes on the stream."""
+        lib = self.lib
+        _hip.check(lib.fn2_fill_zero(_hip.ptr(self.grad_arena), self.grad_arena.numel() * 4, s))
+        for g in self.gbufs.values():
+            if g.data_ptr() not in self._no_zero:
+                _hip.check(lib.fn2_fill_zero(_hip.ptr(g), g.numel() * g.element_size(), s))
+        _hip.check(lib.fn2_fill_zero(_hip.ptr(self.loss_dev), 4, s))
 
     def wait_reduction(self):
         """Block the compute stream on the outstanding bucket all-reduces; returns the number of ranks summed."""
@@ -818,20 +826,16 @@ class FlowNetSTrainer:
         eng, s = self.eng, _hip.stream_ptr()
         nseg = len(self._seg_ends)
         if seg == 0:
-            self.grad_arena.zero_()
-            for g in self.gbufs.values():
-                if g.data_ptr() not in self._no_zero:
-                    g.zero_()
-            self.loss_dev.zero_()
+            self._zero_buffers(s)
             eng.launch()
             # (the label downsampling depends on the input only; as a parallel path beside the forward pass: 5.24 -> 5.29 ms,
             # its two graph edges cost more than the 0.15 ms of small launches they would hide)
-            torch.mul(self.gt, self.gt_scale, out=self._gts)
             for pname, wgt in self.loss_terms.items():
                 pred = eng.outputs[pname]
                 n, h, w, _ = pred.shape
                 label = self._labels[pname]
-                _hip.check(self.lib.fn2_downsample_f32(_hip.ptr(self._gts), _hip.ptr(label), n, self.H, self.W, 2, h, w, s))
+                _hip.check(self.lib.fn2_downsample_scaled_f32(_hip.ptr(self.gt), self.gt_scale, _hip.ptr(label), n, self.H,
+                                                              self.W, 2, h, w, s))
                 _hip.check(self.lib.fn2_epe_loss_grad(_hip.ptr(pred), _hip.ptr(label), _hip.ptr(self._gbuf(pred)),
                                                       _hip.ptr(self.loss_dev), n, h, w, wgt, self.loss_scale, s))
         if seg < nseg:
@@ -866,7 +870,6 @@ class FlowNetSTrainer:
         from .dist import exchange_enabled
         # one segment per gradient bucket when the gradients are exchanged, else a single backward segment
         self._seg_ends = [i for i, _ in self.buckets] if exchange_enabled() else [len(self.bwd_ops) - 1]
-        self._gts = torch.empty_like(self.gt)
         self._labels = {pname: torch.empty_like(self.eng.outputs[pname]) for pname in self.loss_terms}
         for pname in self.loss_terms:
             self._gbuf(self.eng.outputs[pname])  # allocate outside the capture

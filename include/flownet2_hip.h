@@ -125,6 +125,11 @@ int fn2_flow_warp_grad_f32(const float* image, const float* flow, const float* g
 int fn2_downsample_f32(const float* in, float* out, int n, int in_h, int in_w, int c, int out_h,
                        int out_w, void* stream);
 
+/* The same op on (in_scale * in), the product formed per sample in fp32 before it is weighted: FlowNetS.loss downsamples
+ * `flow = flow * 0.05` (flownet_s.py:123-129; 20 * flow in flownet_sd.py:122) -- one pass instead of a scaling pass + the op. */
+int fn2_downsample_scaled_f32(const float* in, float in_scale, float* out, int n, int in_h, int in_w, int c, int out_h,
+                              int out_w, void* stream);
+
 /* tf.image.resize_bilinear(align_corners=True) of (scale * in). */
 int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in_w, int c, int out_h,
                             int out_w, float scale, void* stream);
@@ -290,6 +295,12 @@ int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream);
  * forward and backward-data weight copies of the split-fp16 trainer, re-derived from the fp32 master every step
  * (scale = the power of two of the layer's descriptor, out_scale = 1 / scale). */
 int fn2_to_f16x2(void* dst, const float* src, const int32_t* map, int64_t n, float scale, void* stream);
+/* Housekeeping of the train step on the caller's stream (what tf.gradients' accumulators and tf.zeros do in the
+ * reference graph): zero a gradient buffer; dst += src (the correlation's two input gradients joining the towers'
+ * gradient buffers, correlation.py:17-35); a dense copy of a channel slice of an fp32 NHWC buffer. */
+int fn2_fill_zero(void* dst, int64_t bytes, void* stream);
+int fn2_add_f32(float* dst, const float* src, int64_t n, void* stream);
+int fn2_slice_copy_f32(const fn2_tensor* src, float* dst, void* stream);
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0: derives the weight layouts of the input-gradient convolutions. */
 int fn2_gather_f32(float* dst, const float* src, const int32_t* map, int64_t n, void* stream);
 /* tf.train.AdamOptimizer update of n parameters with g' = grad_scale*g + l2*w (slim l2_regularizer). */

@@ -612,3 +612,30 @@ def test_interp_training_cli(tmp_path):
     saved = W.load_npz(str(tmp_path / "ck" / "flownet_s_interp-2.npz"))
     assert "FlowNetS/conv1/weights" in saved and "FlowNetS/conv1/weights/Adam_1" in saved
     assert not any("/predict_flow" in k and k.endswith("/biases") for k in saved)
+
+
+@pytest.mark.gpu
+def test_loss_surface_through_the_library():
+    """src.losses.average_endpoint_error / mean_endpoint_error / multiscale_loss (FlowNetS.loss, flownet_s.py:122-161;
+    utils.py:209-224, :342-351) as calls into the library (fn2_epe_loss_grad, fn2_downsample_scaled_f32) against the
+    NumPy oracle, and fn2_downsample_scaled_f32 == downsample of the pre-scaled tensor bit for bit."""
+    from src import losses, _hip
+    from src.downsample import downsample
+    from oracle import ops as refops
+    rng = np.random.default_rng(8)
+    lab = rng.standard_normal((3, 24, 32, 2)).astype(np.float32)
+    pred = rng.standard_normal((3, 24, 32, 2)).astype(np.float32)
+    got = float(losses.average_endpoint_error(torch.from_numpy(lab).cuda(), torch.from_numpy(pred).cuda()))
+    assert got == pytest.approx(refm.average_endpoint_error(lab, pred), rel=1e-5)
+    assert float(losses.mean_endpoint_error(lab, pred)) == pytest.approx(refm.mean_endpoint_error(lab, pred), rel=1e-5)
+    gt = np.clip(rng.standard_normal((2, 128, 192, 2)) * 5, -40, 40).astype(np.float32)
+    gt[0, 10:20, 30:50] = np.nan
+    for size in ((2, 3), (8, 12), (32, 48)):
+        a = losses.scaled_downsample(torch.from_numpy(gt).cuda(), 0.05, size).cpu().numpy()
+        b = downsample(torch.from_numpy(gt * np.float32(0.05)).cuda(), list(size)).cpu().numpy()
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, refops.downsample(gt * np.float32(0.05), size), rtol=1e-5, atol=1e-6, equal_nan=True)
+    preds = {"predict_flow%d" % l: torch.from_numpy(rng.standard_normal((2, 128 >> l, 192 >> l, 2)).astype(np.float32)).cuda()
+             for l in (6, 5, 4, 3, 2)}
+    want, _ = refm.multiscale_loss(gt_nonan := np.nan_to_num(gt), {k: v.cpu().numpy() for k, v in preds.items()}, None)
+    assert float(losses.multiscale_loss(gt_nonan, preds)) == pytest.approx(want, rel=1e-5)
