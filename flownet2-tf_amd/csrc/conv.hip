@@ -1327,6 +1327,39 @@ int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, fl
   return FN2_OK;
 }
 
+int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, float out_scale, const float* bias, float* pf,
+                   int ring, void* stream) {
+  int rc = check_view(x, "flow_head5 input");
+  if (rc) return rc;
+  FN2_REQUIRE(wgt && pf, "flow_head5: null pointer");
+  FN2_REQUIRE(x->dtype == FN2_F16X2 && x->cs % 8 == 0 && x->c0 % 8 == 0, "flow_head5: split-fp16 input, 8-aligned view");
+  FN2_REQUIRE(cin_pad % 32 == 0 && cin_pad >= x->c && x->c0 + cin_pad <= x->cs && kpad == cin_pad,
+              "flow_head5: the channel run must be whole 128-byte lines inside the buffer (kpad = cin_pad)");
+  FN2_REQUIRE(!ring || (x->h >= 3 && x->w >= 3), "flow_head5: a border ring needs h, w >= 3");
+  const long in_bytes = (long)x->n * x->h * x->w * x->cs * 4;
+  FN2_REQUIRE(in_bytes < (1L << 31), "flow_head5: input buffer >= 2 GiB is not addressable by the LDS-DMA kernel");
+  ConvArgs a = {};
+  a.in = x->data; a.wgt = wgt; a.bias = bias; a.out = pf;
+  a.N = x->n; a.H = x->h; a.W = x->w; a.in_cs = x->cs; a.in_c0 = x->c0;
+  a.cin_chunks = cin_pad / 4;            // 16-byte chunks per tap (split fp16: 4 channels each)
+  a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+  a.OH = x->h; a.OW = x->w;
+  a.h5_tx = cdiv(x->w, 28); a.h5_ty = cdiv(x->h, 4); a.h5_ring = ring ? 1 : 0;
+  const long blocks = (long)x->n * a.h5_ty * a.h5_tx;
+  FN2_REQUIRE(blocks * 256 < (1L << 31), "flow_head5: too many tiles");
+  a.M = (int)(blocks * 256);
+  a.out_H = x->h; a.out_W = x->w; a.out_cs = 2; a.out_c0 = 0; a.Cout = 2;
+  a.ksteps = cin_pad / 32;               // 128-byte stages per packed row
+  a.cout_pad = 64;
+  a.act = FN2_ACT_NONE;
+  a.kh_ph[0] = a.kh_ph[1] = a.kw_ph[0] = a.kw_ph[1] = 1;
+  a.kg = 1; a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = 4;
+  a.out_scale = out_scale == 0.f ? 1.f : out_scale;
+  a.in_bytes = (int)in_bytes;
+  a.dbg = 0;                             // (XCD-aware order: each XCD walks a contiguous run of tiles, halos stay in its L2)
+  return launch_head5(a, (int)blocks, (hipStream_t)stream);
+}
+
 int fn2_flow_head_ring(const fn2_tensor* x, const float* wc, const float* bc, float* pf, void* stream) {
   int rc = check_view(x, "flow_head_ring input");
   if (rc) return rc;

@@ -73,6 +73,13 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
                :: "s"(la), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// HEAD5 epilogue: word w of the partial-sum table T, which spans the two stage buffers (two LDS objects of `half` bytes)
+__device__ __forceinline__ float* h5_t(uint4* a, uint4* b, int half, int w) {
+  const int byte = w * 4;
+  return byte < half ? reinterpret_cast<float*>(reinterpret_cast<char*>(a) + byte)
+                     : reinterpret_cast<float*>(reinterpret_cast<char*>(b) + (byte - half));
+}
+
 // TCN = 32-cout MFMA tiles per wave (2: the 128x128 / 64x256 blocks; 1: a 32-cout x 256-pixel block for the
 // Cout <= 32 layers -- full-resolution fusion layers, conv_redir -- whose 64-cout tile was half or more padding).
 // TPN = 32-pixel MFMA tiles per wave (1: a 128-cout x 64-pixel block for mid-size layers whose 128 x 128 grid
@@ -95,10 +102,15 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
 // couts x the whole pixel tile: no weight byte is fetched twice).  Against the 2 x 2 layout of the same 128 x 64 tile:
 // LDS-DMA pieces per wave and stage 6 -> 2 (their issue cost, ~60-180 cycles each, is what a wave spends besides its
 // 384 cycles of MFMAs), LDS writes 24 -> 8 KB and fragment reads 48 -> 32 KB per stage, the same 24 KB through L1.
+// HEAD5 = the composed 5x5 two-output flow head (interconvN + predict_flowN as one convolution, fn2_flow_head5 in
+// flownet2_hip.h) on the 64-cout x 256-pixel tile: the block's 256 "pixels" are the 8 x 32 positions of a 4 x 28 output
+// tile + 2 halo (out-of-image positions are zero rows), the GEMM is the 1x1 product to the 50 (tap, output) partials of
+// every position, and the epilogue -- instead of storing them -- puts the partials in LDS (the stage buffers are free),
+// sums the 25 shifted partials of each output pixel and writes the two flow channels.
 // SLAB (WREG instantiations only) = the launch is a K split: the epilogue is the partial-sum slab store and nothing else
 // (without it a WREG instantiation has no slab code at all); the other instantiations decide at run time.
 template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2, int KG = 1, bool M16 = false,
-          bool WREG = false, bool SLAB = false>
+          bool WREG = false, bool SLAB = false, bool HEAD5 = false>
 __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
@@ -196,11 +208,19 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   for (int j = 0; j < NPI; ++j) {
     const int row = wave * (BP / 4) + j * 8 + lrow;
     const int m = m0 + row;
-    const bool v = m < p.M;
+    bool v = m < p.M;
     const int mm = v ? m : 0;
-    const int n = mm / (p.OH * p.OW);
+    int n = mm / (p.OH * p.OW);
     const int rem = mm - n * (p.OH * p.OW);
-    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    int oy = rem / p.OW, ox = rem - oy * p.OW;
+    if constexpr (HEAD5) {  // row = position (ry, rx) of the block's 8 x 32 window; bx = (n, tile row, tile column)
+      static_assert(BP == 256, "HEAD5: 8 x 32 positions per block");
+      const int tx = bx % p.h5_tx, tyn = bx / p.h5_tx;
+      n = tyn / p.h5_ty;
+      oy = (tyn - n * p.h5_ty) * 4 - 2 + (row >> 5);
+      ox = tx * 28 - 2 + (row & 31);
+      v = true;  // (positions outside the image fail the range test below: zero rows)
+    }
     const int iy0 = oy * p.stride - pad_y, ix0 = ox * p.stride - pad_x;
     roff[j] = (((n * p.H + iy0) * p.W + ix0) * p.in_cs + p.in_c0) * ESZ + (lphys ^ ((row >> 1) & 7)) * 16;
     unsigned mk = 0;
@@ -576,6 +596,44 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
       }
   }
 
+  if constexpr (HEAD5) {
+    // partials -> LDS as T[position][52] (50 used: (uy * 5 + ux) * 2 + o), then the 25-tap sums.  The two-stage loop ended
+    // with a barrier, so the stage buffers (2 x (64 + 256) x 128 B) are free.
+    constexpr int TS = 52;
+    static_assert(256 * TS * 4 <= 2 * ROWS * 128, "T fits the stage buffers");
+#pragma unroll
+    for (int tc = 0; tc < TCN; ++tc)
+#pragma unroll
+      for (int tp = 0; tp < TPN; ++tp) {
+        const int pos = wp * TPN * 32 + tp * 32 + fr;
+        const int cb = tc * 32 + fh * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (cb + 4 * q < TS)
+            *reinterpret_cast<float4*>(h5_t(lds0_all, lds1_all, ROWS * 128, pos * TS + cb + 4 * q)) =
+                make_float4(acc[tc][tp][4 * q] * p.out_scale, acc[tc][tp][4 * q + 1] * p.out_scale,
+                            acc[tc][tp][4 * q + 2] * p.out_scale, acc[tc][tp][4 * q + 3] * p.out_scale);
+      }
+    __syncthreads();
+    const int tx = bx % p.h5_tx, tyn = bx / p.h5_tx;
+    const int n = tyn / p.h5_ty, ty = tyn - n * p.h5_ty;
+    float* pf = reinterpret_cast<float*>(p.out);
+    if (tid < 224) {  // 4 x 28 output pixels x 2 flow channels
+      const int o = tid & 1, px = tid >> 1;
+      const int py = px / 28, pxx = px - py * 28;
+      const int oy = ty * 4 + py, ox = tx * 28 + pxx;
+      if (oy < p.OH && ox < p.OW && !(p.h5_ring && (oy == 0 || oy == p.OH - 1 || ox == 0 || ox == p.OW - 1))) {
+        float a = p.bias ? p.bias[o] : 0.f;
+#pragma unroll
+        for (int uy = 0; uy < 5; ++uy)
+#pragma unroll
+          for (int ux = 0; ux < 5; ++ux)
+            a += *h5_t(lds0_all, lds1_all, ROWS * 128, ((py + uy) * 32 + pxx + ux) * TS + (uy * 5 + ux) * 2 + o);
+        pf[(((size_t)n * p.OH + oy) * p.OW + ox) * 2 + o] = a;
+      }
+    }
+    return;
+  }
   if (FN2_CONV_ABLATE && (p.dbg & 262144)) return;  // ablation: no epilogue
   if constexpr (M16) {
     // D of a 16 x 16 sub-tile: column (pixel) = lane & 15, rows (packed weight rows) 4 (lane >> 4) + j.  With the row
@@ -1392,6 +1450,13 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   else FN2_LAUNCH2(cdiv(a.M, 256), a.cout_pad / 32, 256, 1, 4, 1, 2, 2, 1);
 #undef FN2_LAUNCH2
   FN2_CHECK_LAUNCH("conv_igemm2");
+  return FN2_OK;
+}
+
+int launch_head5(const ConvArgs& a, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL((conv_igemm2_kernel<x2_t, float, 1, 4, 2, 2, 2, 1, false, false, false, true>), dim3(blocks, 1, 1), dim3(256), 0,
+                     s, a);
+  FN2_CHECK_LAUNCH("flow_head5");
   return FN2_OK;
 }
 

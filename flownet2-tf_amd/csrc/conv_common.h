@@ -26,6 +26,7 @@ struct ConvArgs {
   int bp64;     // LDS-DMA kernel: half-width pixel tiles (128x64 / 64x128 / 32x128), see wants_bp64 in conv.hip
   int KH_KW_hint;  // kind 2 (row-run stems): the real kernel width KW (KW itself is 1 there: a kernel row is one "tap"); else 0
   int kg;       // LDS-DMA kernel, 128 x 64 tiles: K groups per block (1, 2 or 3; conv2.hip), see build_args in conv.hip
+  int h5_tx, h5_ty, h5_ring;  // composed 5x5 flow head (conv2.hip, HEAD5): tiles per image row / column, ring pixels pre-written
   int wfrag;    // 1: the weight is stored in MFMA-fragment order (wgt_layout 2) and loaded straight into registers (conv2.hip, WREG)
   int accum;    // 1: out += result (fp32 outputs; gradient accumulation into shared buffers)
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
@@ -98,6 +99,8 @@ ConvNameSink& conv_name_sink();
 
 // conv2.hip: the fast path.  Returns FN2_ERR_UNSUPPORTED when (dtype, tile) has no instantiation.
 int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s);
+// conv2.hip: the composed 5x5 flow head (HEAD5 instantiation); `blocks` = n * tiles_y * tiles_x
+int launch_head5(const ConvArgs& a, int blocks, hipStream_t s);
 // true when the fast kernel covers this geometry (then the packed weight must use the permuted-64 row order)
 bool conv_fast_ok(int in_dtype, int cin_pad, int cout);
 

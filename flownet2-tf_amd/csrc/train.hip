@@ -190,8 +190,21 @@ __global__ void __launch_bounds__(256) act_bias_bwd_x2_kernel(const x2_t* __rest
 
 // fp32 -> split fp16 with a power-of-two scale (the forward / backward weight copies of the f16x2 trainer are
 // derived from the fp32 master every step); map != nullptr: gathered, dst[i] = map[i] >= 0 ? src[map[i]] : 0.
+// Where the (hi, lo) 16-byte chunks of 8-element group g of a packed [rows][K] weight (K % 32 == 0) live in the split-fp16
+// image: row-major (fn2_conv2d wgt_layout 1: hi at chunk 2 g, lo right behind it) or MFMA-fragment order (wgt_layout 2,
+// conv2.hip WREG: per 32-row tile and 128-byte stage four 1 KiB blocks f = 2 q + part, lane 32 h + r of a block holds
+// chunk 4 q + 2 h + part of row r; the lo chunk is the same lane of the next block).  Returns 16-byte chunk indices.
+__device__ __forceinline__ void x2_chunks(long g, int frag_k, long& hi, long& lo) {
+  if (frag_k == 0) { hi = 2 * g; lo = 2 * g + 1; return; }
+  const int gpr = frag_k >> 3;                      // groups per row
+  const long row = g / gpr;
+  const int gk = (int)(g - row * gpr), st = gk >> 2, gs = gk & 3;
+  hi = (((row >> 5) * (frag_k >> 5) + st) * 4 + (gs >> 1) * 2) * 64 + (gs & 1) * 32 + (row & 31);
+  lo = hi + 64;
+}
+
 __global__ void __launch_bounds__(256) to_x2_kernel(const float* __restrict__ src, const int* __restrict__ map,
-                                                    x2_t* __restrict__ dst, long ngroups, float scale) {
+                                                    x2_t* __restrict__ dst, long ngroups, float scale, int frag_k) {
   for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (long)gridDim.x * blockDim.x) {
     float v[8];
 #pragma unroll
@@ -199,8 +212,10 @@ __global__ void __launch_bounds__(256) to_x2_kernel(const float* __restrict__ sr
       if (map != nullptr) { const int m = map[gi * 8 + j]; v[j] = m >= 0 ? src[m] * scale : 0.f; }
       else v[j] = src[gi * 8 + j] * scale;
     }
-    uint4* q = reinterpret_cast<uint4*>(dst + gi * 8);
-    split8(v, q[0], q[1]);
+    long hi, lo;
+    x2_chunks(gi, frag_k, hi, lo);
+    uint4* q = reinterpret_cast<uint4*>(dst);
+    split8(v, q[hi], q[lo]);
   }
 }
 
@@ -284,7 +299,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ w, float*
 // (16-byte accesses; every tensor starts 16-byte aligned).  tab[t] = {w, m, v, g} pointers + the split-fp16 forward
 // copy of the weight (or null) and its power-of-two scale: the copy the convolutions read is written by the same pass
 // that updates the fp32 master.  n[t] elements, l2[t] regulariser (0 for biases / transposed convs).
-struct AdamTensor { float* w; float* m; float* v; const float* g; x2_t* wx2; float scale; int pad_; };
+struct AdamTensor { float* w; float* m; float* v; const float* g; x2_t* wx2; float scale; int frag_k; };  // frag_k: see x2_chunks
 static_assert(sizeof(AdamTensor) == 48, "the host builds the table as six 64-bit words per tensor");
 __device__ __forceinline__ void adam_tensor(const AdamTensor& t, long cnt, float reg, float lr_t, float b1, float b2,
                                             float eps, float gscale) {
@@ -305,7 +320,19 @@ __device__ __forceinline__ void adam_tensor(const AdamTensor& t, long cnt, float
     reinterpret_cast<float4*>(t.w)[i] = w;
     if (t.wx2 != nullptr) {
       const float o[4] = {w.x * t.scale, w.y * t.scale, w.z * t.scale, w.w * t.scale};
-      store_vec<x2_t, 4>(t.wx2 + 4 * i, o);
+      if (t.frag_k == 0) {
+        store_vec<x2_t, 4>(t.wx2 + 4 * i, o);
+      } else {  // elements 4 i .. 4 i + 3 = half of group i / 2: 8 bytes of its hi chunk, 8 bytes of its lo chunk
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        h4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = (_Float16)o[j]; l[j] = (_Float16)(o[j] - (float)h[j]); }
+        long ch, cl;
+        x2_chunks(i >> 1, t.frag_k, ch, cl);
+        char* base = reinterpret_cast<char*>(t.wx2);
+        *reinterpret_cast<h4*>(base + ch * 16 + (i & 1) * 8) = h;
+        *reinterpret_cast<h4*>(base + cl * 16 + (i & 1) * 8) = l;
+      }
     }
   }
   for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
@@ -1138,8 +1165,18 @@ int fn2_to_f16x2(void* dst, const float* src, const int32_t* map, int64_t n, flo
   FN2_REQUIRE(dst && src && n >= 0 && n % 8 == 0, "to_f16x2: n must be a multiple of 8 (whole groups)");
   if (n == 0) return FN2_OK;
   hipLaunchKernelGGL(to_x2_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, map, (x2_t*)dst,
-                     (long)(n / 8), scale);
+                     (long)(n / 8), scale, 0);
   FN2_CHECK_LAUNCH("to_f16x2");
+  return FN2_OK;
+}
+
+int fn2_to_f16x2_frag(void* dst, const float* src, const int32_t* map, int64_t n, float scale, int k, void* stream) {
+  FN2_REQUIRE(dst && src && n >= 0 && k > 0 && k % 32 == 0 && n % ((int64_t)k * 32) == 0,
+              "to_f16x2_frag: a packed [rows][k] weight with k %% 32 == 0 and rows %% 32 == 0");
+  if (n == 0) return FN2_OK;
+  hipLaunchKernelGGL(to_x2_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, map, (x2_t*)dst,
+                     (long)(n / 8), scale, k);
+  FN2_CHECK_LAUNCH("to_f16x2_frag");
   return FN2_OK;
 }
 

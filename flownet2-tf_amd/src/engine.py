@@ -156,6 +156,9 @@ class Engine:
         # loads them straight into registers (conv2.hip, WREG).  Not for the trainer (the filter-gradient kernels write
         # layout 1).  None: FN2_WREG (default on).
         self.fragment_weights = bool(int(os.environ.get("FN2_WREG", "1"))) if fragment_weights is None else bool(fragment_weights)
+        # compose_heads: FlowNetSD's / the fusion net's linear interconvN + predict_flowN pairs run as one composed 5x5
+        # head (_composed_head).  Inference engines only (the trainer needs both variables); FN2_COMPOSE=0: off (A/B).
+        self.compose_heads = bool(heads_as_gemm) and dtype == "f16x2" and bool(int(os.environ.get("FN2_COMPOSE", "1")))
         self._head_t = None
         self.outputs = self._build()
         self._check_variables(strict)
@@ -308,20 +311,23 @@ class Engine:
         d.cin_pad, d.cout_pad, d.kpad = cin_pad, cout_pad, kpad
         d.wgt_layout = layout
         d.out_scale = out_scale
+        frag = False
         if (self.fragment_weights and layout == 1 and tile >= int(os.environ.get("FN2_WREG_TILE_MIN", "128"))
                 and plan.wgt_dtype == _hip.FN2_F16X2 and self._wants_fragments(d)):
             wdev = W.to_fragment_order(wdev)
-            d.wgt, d.wgt_layout, layout = wdev.data_ptr(), 2, 2
+            d.wgt, d.wgt_layout, frag = wdev.data_ptr(), 2, True
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
         self.desc_branch.append(self._branch)
+        # (layout = how the fp32 packed matrix is ordered -- what the trainer's index maps and filter gradients use;
+        # frag = the split-fp16 copy `w` the forward launch reads is that matrix re-tiled into fragment order)
         self.layers.append(dict(scope=scope, name=name, kind=d.kind, k=k, stride=stride, pad=pad, cin=cin, cout=cout,
                                 act=bool(act), src=src, dst=dst, desc=d, w=wdev, b=bias, cin_pad=cin_pad,
-                                cout_pad=cout_pad, kpad=kpad, layout=layout, tile=tile, kstep=plan.kstep_elems))
+                                cout_pad=cout_pad, kpad=kpad, layout=layout, tile=tile, kstep=plan.kstep_elems, frag=frag))
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         if kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1:
             kern = f"flow_head_kernel<{tn}>"
-        elif layout >= 1:
+        elif layout == 1:
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
             m_px = dbuf.shape[0] * dbuf.shape[1] * dbuf.shape[2] // (4 if kind != "conv" else 1)
             kern = f"conv_igemm2_kernel<{tn}, {on}, {conv2_kernel_args(tile, m_px, cout_pad, 4 if kind != 'conv' else 1, tn == 'fn2::x2_t')}>"
@@ -413,6 +419,100 @@ class Engine:
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
         self.layer_io_bytes.append((f"{scope}/{name}", float(n * h * wd * (cin * esz + 2 * 4) + 18 * cin * esz)))
         return True
+
+    def _composed_head(self, scope, ic_spec, pf_spec, src, pf, up=None):
+        """interconvN (3x3, linear) + predict_flowN (3x3, linear) of FlowNetSD's decoder and the FlowNet2 fusion net
+        (flownet_sd.py:60-64 ..., flownet2.py:74-77, :90-93) as ONE 5x5 two-output convolution of the concat buffer with
+        the composed weights (src.weights.compose_interconv_head): the interconv's output -- dec_c channels at the
+        level's resolution, read by nothing but the head -- is never formed.  Three launches: the border ring with its
+        per-case weights (fn2_flow_head_ring), a 1x1 GEMM to the 50 (tap, output) partials of a pixel, and the tail
+        (fn2_flow_head_tail: 25 shifted partials + bias, ring pixels taken from the first launch, + the upsample_flow
+        that follows the head).  Returns 0 (nothing emitted) when the input slice does not fit the GEMM kernel, 2 when the
+        head took `up` into its tail launch, 1 when the caller still has to emit that upsample_flow."""
+        sbuf, sc0, sc = src
+        in_code = self._code(sbuf)
+        if in_code != _hip.FN2_F16X2 or sc0 % 8 or sbuf.shape[1] < 3 or sbuf.shape[2] < 3:
+            return False
+        cin_line = _round_up(sc, 32)
+        if sc0 + cin_line > sbuf.shape[3]:
+            return False
+        plan = _hip.conv_plan(in_code, cin_line, 50)
+        if plan.layout != 1:
+            return False
+        ic_name, pf_name = ic_spec[0], pf_spec[0]
+        w1, w2 = self._w(f"{scope}/{ic_name}/weights"), self._w(f"{scope}/{pf_name}/weights")
+        b1 = self._w(f"{scope}/{ic_name}/biases") if netdefs.has_bias(self.model, ic_name, "conv", self.no_deconv_biases) else None
+        b2 = self._w(f"{scope}/{pf_name}/biases") if netdefs.has_bias(self.model, pf_name, "conv", self.no_deconv_biases) else None
+        w5, bias5 = W.compose_interconv_head(w1, b1, w2, b2)
+        n, h, wd = pf.shape[0], pf.shape[1], pf.shape[2]
+        # ---- border ring: fp32 weights [9][25][8 * groups][2], zero on the pad channels
+        groups = (sc + 7) // 8
+        wc = np.zeros((9, 25, groups * 8, 2), np.float32)
+        wc[:, :, :sc, :] = w5.reshape(9, 25, sc, 2)
+        wcd = W.to_device(wc, torch.float32, self.device)
+        bcd = W.to_device(bias5.astype(np.float32), torch.float32, self.device)
+        vin = self._v(sbuf, sc, sc0)
+        self.keep += [wcd, bcd, vin]
+        self._op(f"{scope}/{pf_name}/ring", self.lib.fn2_flow_head_ring, C.byref(vin), _hip.ptr(wcd), _hip.ptr(bcd), _hip.ptr(pf),
+                 kernel="flow_head_ring")
+        # ---- interior: 1x1 GEMM with 50 outputs (tap * 2 + o), then the 25-tap tail
+        w1x1 = np.ascontiguousarray(w5[4].transpose(2, 0, 1, 3)).reshape(1, 1, sc, 50).astype(np.float32)
+        packed, cin_pad, cout_pad, kpad = W.pack_conv(w1x1, plan.cout_tile, plan.kstep_elems, cin_line, plan.layout)
+        out_scale = 1.0
+        wmax = float(abs(packed).max())
+        if wmax > 0:
+            k2 = int(math.floor(math.log2(1024.0 / wmax)))
+            packed, out_scale = packed * (2.0 ** k2), 2.0 ** (-k2)
+        wdev = W.packed_to_device(packed, plan.wgt_dtype, self.device)
+        cm = ic_spec[6]
+        if n * h * wd >= int(os.environ.get("FN2_HEAD5_MIN", "65536")) and plan.cout_tile == 64 and kpad == cin_pad:
+            # large maps: GEMM and tail in one launch, the partials stay in LDS (fn2_flow_head5); the upsample_flow that
+            # follows is then its own launch (the caller's)
+            b5 = W.to_device(bias5[4].astype(np.float32), torch.float32, self.device)
+            vx = self._v(sbuf, sc, sc0)
+            self.keep += [wdev, b5, vx]
+            self._op(f"{scope}/{ic_name}+{pf_name}", self.lib.fn2_flow_head5, C.byref(vx), _hip.ptr(wdev), cin_pad, kpad,
+                     C.c_float(out_scale), _hip.ptr(b5), _hip.ptr(pf), 1,
+                     kernel="conv_igemm2_kernel<fn2::x2_t, float, 1, 4, 2, 2, 2, 1, false, false, false, true>")
+            self.layer_flops.append((f"{scope}/{ic_name}+{pf_name}", 2.0 * n * h * wd * 9 * (sc * cm + cm * 2)))
+            self.layer_io_bytes.append((f"{scope}/{ic_name}+{pf_name}", float(n * h * wd * (sc * 4 + 2 * 4) + 9 * (sc * cm + 2 * cm) * 4)))
+            return 1
+        if self._head_t is None:
+            self._head_t = {}
+        key = (self._branch, 64)
+        if key not in self._head_t:
+            self._head_t[key] = torch.zeros((self.N * self.H * self.W, 64), dtype=torch.float32, device=self.device)
+        head_t = self._head_t[key]
+        d = _hip.Fn2ConvDesc()
+        d.inp = self._v(sbuf, sc, sc0)
+        d.out = _hip.Fn2Tensor(head_t.data_ptr(), _hip.FN2_F32, n, h, wd, 50, 64, 0)
+        d.wgt, d.bias = wdev.data_ptr(), None
+        d.kind, d.kh, d.kw, d.stride, d.pad = 0, 1, 1, 1, 0
+        d.act = _hip.ACT_NONE
+        d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, plan.layout
+        d.out_scale = out_scale
+        b5 = W.to_device(bias5[4].astype(np.float32), torch.float32, self.device)
+        self.keep += [d, wdev, b5]
+        self.conv_descs.append(d)
+        self.desc_branch.append(self._branch)
+        self._op(f"{scope}/{ic_name}+{pf_name}", self.lib.fn2_conv2d, C.byref(d), kernel="conv_igemm2_kernel (composed head)")
+        if up is not None:
+            up_name, (ubuf, uc0, uc) = up
+            uw = W.to_device(self._w(f"{scope}/{up_name}/weights"), torch.float32, self.device)
+            ub = self._bias(scope, up_name, "deconv", 2)
+            uv = self._v(ubuf, uc, uc0)
+            self.keep += [uw, ub, uv]
+            self.layers.append(dict(scope=scope, name=up_name, kind="upflow", src=pf, dst=up[1], w=uw, b=ub, view=uv))
+            self._op(f"{scope}/{pf_name}/tail+{up_name}", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 64, 5, _hip.ptr(b5),
+                     _hip.ptr(pf), n, h, wd, 1, _hip.ptr(uw), _hip.ptr(ub) if ub is not None else None, C.byref(uv),
+                     kernel="flow_head_tail")
+        else:
+            self._op(f"{scope}/{pf_name}/tail", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 64, 5, _hip.ptr(b5), _hip.ptr(pf),
+                     n, h, wd, 1, None, None, None, kernel="flow_head_tail")
+        # algorithmic work = what the reference graph does (two 3x3 convolutions), whatever form executes it
+        self.layer_flops.append((f"{scope}/{ic_name}+{pf_name}", 2.0 * n * h * wd * 9 * (sc * cm + cm * 2)))
+        self.layer_io_bytes.append((f"{scope}/{ic_name}+{pf_name}", float(n * h * wd * (sc * 4 + 2 * 4) + 9 * (sc * cm + 2 * cm) * 4)))
+        return 2 if up is not None else 1
 
     def _conv_stem(self, scope, spec, sbuf, dst, s2d=False):
         """First layer of a network on its pre-padded few-channel input: kind-2 row-run convolution
@@ -542,15 +642,23 @@ class Engine:
                 self._sync(Hd, M)  # ... and for the head (with an interconv the head waits for that instead)
             cur, cur_c = cat, skip_c + dec_c + 2
             head_src = (cat, 0, cur_c)
+            pf = self._buf(f"{tag}/predict_flow{lvl}", N, h, w, 2, torch.float32)
+            up = None
+            if lvl > 2:
+                up = (f"upsample_flow{lvl}to{lvl - 1}", (cats[lvl - 1], skips[i + 1] + decs[i + 1], 2))
+            if interconv and self.compose_heads:
+                self._sync(Hd, M)
+                with self._lane(Hd):
+                    composed = self._composed_head(scope, L[f"interconv{lvl}"], L[f"predict_flow{lvl}"], head_src, pf, up=up)
+                if composed:
+                    fused = composed == 2
+                    preds[f"predict_flow{lvl}"] = pf
+                    continue
             if interconv:
                 ic = self._buf(f"{tag}/interconv{lvl}", N, h, w, dec_c)
                 self._conv(scope, L[f"interconv{lvl}"], (cat, 0, cur_c), (ic, 0, dec_c))
                 self._sync(Hd, M)
                 head_src = (ic, 0, dec_c)
-            pf = self._buf(f"{tag}/predict_flow{lvl}", N, h, w, 2, torch.float32)
-            up = None
-            if lvl > 2:
-                up = (f"upsample_flow{lvl}to{lvl - 1}", (cats[lvl - 1], skips[i + 1] + decs[i + 1], 2))
             with self._lane(Hd):
                 fused = self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2), up=up)
             preds[f"predict_flow{lvl}"] = pf
@@ -751,22 +859,31 @@ class Engine:
             with self._lane(Hd):
                 self._upflow(scope, "fuse_upsample_flow2to1", pf2, (cat1, 160, 2))
         self._sync(M, Hd)
-        ic1 = self._buf(f"{tag}/fuse_interconv1", N, H // 2, W_ // 2, 32)
-        self._conv(scope, L["fuse_interconv1"], (cat1, 0, 162), (ic1, 0, 32))
-        self._sync(Hd, M)
         pf1 = self._buf(f"{tag}/predict_flow1", N, H // 2, W_ // 2, 2, torch.float32)
-        with self._lane(Hd):
-            fused = self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2),
-                               up=("fuse_upsample_flow1to0", (cat0, 80, 2)))
+        fused, composed = None, 0
+        if self.compose_heads:
+            self._sync(Hd, M)
+            with self._lane(Hd):
+                composed = self._composed_head(scope, L["fuse_interconv1"], L["predict_flow1"], (cat1, 0, 162), pf1,
+                                               up=("fuse_upsample_flow1to0", (cat0, 80, 2)))
+            fused = composed == 2
+        if not composed:
+            ic1 = self._buf(f"{tag}/fuse_interconv1", N, H // 2, W_ // 2, 32)
+            self._conv(scope, L["fuse_interconv1"], (cat1, 0, 162), (ic1, 0, 32))
+            self._sync(Hd, M)
+            with self._lane(Hd):
+                fused = self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2),
+                                   up=("fuse_upsample_flow1to0", (cat0, 80, 2)))
         self._conv(scope, L["fuse_deconv0"], (cat1, 0, 162), (cat0, 64, 16))
         if not fused:
             with self._lane(Hd):
                 self._upflow(scope, "fuse_upsample_flow1to0", pf1, (cat0, 80, 2))
         self._sync(M, Hd)
-        ic0 = self._buf(f"{tag}/fuse_interconv0", N, H, W_, 16)
-        self._conv(scope, L["fuse_interconv0"], (cat0, 0, 82), (ic0, 0, 16))
         pf0 = self._buf(f"{tag}/predict_flow0", N, H, W_, 2, torch.float32)
-        self._conv(scope, L["predict_flow0"], (ic0, 0, 16), (pf0, 0, 2))
+        if not (self.compose_heads and self._composed_head(scope, L["fuse_interconv0"], L["predict_flow0"], (cat0, 0, 82), pf0)):
+            ic0 = self._buf(f"{tag}/fuse_interconv0", N, H, W_, 16)
+            self._conv(scope, L["fuse_interconv0"], (cat0, 0, 82), (ic0, 0, 16))
+            self._conv(scope, L["predict_flow0"], (ic0, 0, 16), (pf0, 0, 2))
         # resize_bilinear to (height, width) of a full-resolution tensor is the identity (flownet2.py:100-101)
         return {"predict_flow0": pf0, "flow": pf0}
 

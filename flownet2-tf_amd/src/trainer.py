@@ -112,8 +112,12 @@ class FlowNetSTrainer:
             self.loss_terms, self.gt_scale = {"predict_flow0": 1.0}, 1.0
             if self.hfem:
                 raise ValueError("hard-flow-example mining belongs to FlowNetS_interp")
+        # FN2_TRAIN_WREG=1: the split-fp16 COPIES the convolutions read are kept in MFMA-fragment order where the library
+        # has the register-operand kernel (masters, gradients and Adam state stay row-major).  Off by default: the
+        # convolutions gain 0.09 ms per step (batch 8) but the per-step refresh of those copies -- Adam's 8-byte pieces and
+        # the gathers' 16-byte chunks scattered over the fragment blocks -- costs 0.25 ms: 4.76 -> 4.92 ms.
         self.eng = Engine(model, weights, batch, height, width, dtype, heads_as_gemm=False, plain_stems=True,
-                          fragment_weights=False)  # (the filter-gradient kernels write the row-major packed layout)
+                          fragment_weights=self.x2 and bool(int(os.environ.get("FN2_TRAIN_WREG", "0"))))
         self.lib, self.dev = self.eng.lib, self.eng.device
         self.N, self.H, self.W = batch, height, width
         self.schedule, self.eps = schedule, eps
@@ -195,7 +199,7 @@ class FlowNetSTrainer:
             rec["master"] = self._master(rec)
             if rec["master"] is not rec["w"]:
                 rec["scale"] = 1.0 / float(rec["desc"].out_scale)
-                self.fwd_copies.append((rec["w"], rec["master"], rec["scale"]))
+                self.fwd_copies.append((rec["w"], rec["master"], rec["scale"], rec["kpad"] if rec.get("frag") else 0))
             params.append((rec["master"], reg, rec))
             if rec.get("b") is not None:
                 params.append((rec["b"], False, None))
@@ -278,7 +282,7 @@ class FlowNetSTrainer:
         wf = torch.zeros(gmap.numel(), dtype=torch.float32, device=self.dev)  # split fp16 in an fp32 container
         wmax = float(rec["master"].abs().max().item())
         scale = 2.0 ** int(math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 1.0
-        self.gathers.append((wf, rec["master"], gmap, scale))
+        self.gathers.append([wf, rec["master"], gmap, scale, 0])
         n, h, w = int(pf.shape[0]), int(pf.shape[1]), int(pf.shape[2])
         t18 = torch.zeros((n * h * w, 32), dtype=torch.float32, device=self.dev)
         d = _hip.Fn2ConvDesc()
@@ -425,7 +429,8 @@ class FlowNetSTrainer:
         gmap = torch.from_numpy((pk.reshape(-1) - 1.0).astype(np.int32)).to(self.dev)
         wb = torch.zeros(gmap.numel(), dtype=torch.float32, device=self.dev)  # fp32, or split fp16 in an fp32 container
         scale = rec.get("scale", 1.0)
-        self.gathers.append((wb, rec["master"], gmap, scale))
+        gather = [wb, rec["master"], gmap, scale, 0]   # (last: packed row length when the copy is in fragment order)
+        self.gathers.append(gather)
         d = _hip.Fn2ConvDesc()
         d.inp = self._view(gy_buf, gy_c, gy_c0)
         d.out = self._view(gx_buf, gx_c, gx_c0)
@@ -435,6 +440,8 @@ class FlowNetSTrainer:
         d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout = cin_pad, cout_pad, kpad, plan.layout
         d.accumulate = 1
         d.out_scale = 1.0 / scale
+        if self.eng.fragment_weights and plan.layout == 1 and plan.cout_tile == 128 and self.eng._wants_fragments(d):
+            d.wgt_layout, gather[4] = 2, kpad   # the gather writes this copy in MFMA-fragment order
         self.keep += [d, wb, gmap]
         self.eng.conv_descs.append(d)  # shares the split-K workspace
         tn = "fn2::x2_t" if self.x2 else "float"
@@ -583,7 +590,9 @@ class FlowNetSTrainer:
             for fn, args in ops:
                 fl, kern = 0.0, fn.__name__.replace("fn2_", "") + "_kernel"
                 if fn is self.lib.fn2_conv2d:
-                    fl, kern = flops.get(name, 0.0), args[0]._obj.kernel_name
+                    buf = C.create_string_buffer(256)  # the instantiation the library takes (tile, ring, fragment order, split)
+                    rc = self.lib.fn2_conv2d_kernel_name(args[0], buf, 256)
+                    fl, kern = flops.get(name, 0.0), (buf.value.decode() if rc == 0 and buf.value else args[0]._obj.kernel_name)
                 elif fn is self.lib.fn2_conv2d_bwd_filter:
                     fl, kern = flops.get(name, 0.0), ("bwd_filter_x2_kernel" if self.x2 else "bwd_filter_kernel")
                 out.append(("bwd " + name, fn, args, kern, fl))
@@ -594,14 +603,19 @@ class FlowNetSTrainer:
         """Derive every weight copy the convolutions read from the fp32 masters: the transposed / phase-decomposed
         layouts of the input-gradient convolutions and, in the f16x2 trainer, the split-fp16 forward weights."""
         s = _hip.stream_ptr()
-        for wb, wsrc, gmap, scale in self.gathers:
-            if self.x2:
+        for wb, wsrc, gmap, scale, frag_k in self.gathers:
+            if self.x2 and frag_k:
+                _hip.check(self.lib.fn2_to_f16x2_frag(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), scale, frag_k, s))
+            elif self.x2:
                 _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), scale, s))
             else:
                 _hip.check(self.lib.fn2_gather_f32(_hip.ptr(wb), _hip.ptr(wsrc), _hip.ptr(gmap), wb.numel(), s))
         if forward:  # (after an Adam step the forward copies are already fresh: fn2_adam_step_multi writes them)
-            for wx2, master, scale in self.fwd_copies:
-                _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wx2), _hip.ptr(master), None, master.numel(), scale, s))
+            for wx2, master, scale, frag_k in self.fwd_copies:
+                if frag_k:
+                    _hip.check(self.lib.fn2_to_f16x2_frag(_hip.ptr(wx2), _hip.ptr(master), None, master.numel(), scale, frag_k, s))
+                else:
+                    _hip.check(self.lib.fn2_to_f16x2(_hip.ptr(wx2), _hip.ptr(master), None, master.numel(), scale, s))
 
     def learning_rate(self, step):
         """Piecewise-constant schedules and the computed policies (CLR, one-cycle, exponential, LR range test):
@@ -856,11 +870,11 @@ class FlowNetSTrainer:
         """{w, m, v, g, split-fp16 forward copy of w (or 0), its scale} per parameter tensor (fn2_adam_step_multi): Adam
         rewrites the copy the forward convolutions read while it has the new master in registers."""
         l2 = self.schedule["l2_regularization"]
-        fwd = {master.data_ptr(): (wx2.data_ptr(), scale) for wx2, master, scale in self.fwd_copies}
+        fwd = {master.data_ptr(): (wx2.data_ptr(), scale, frag_k) for wx2, master, scale, frag_k in self.fwd_copies}
         ptrs = []
         for p in self.params:
-            wx2, scale = fwd.get(p["w"].data_ptr(), (0, 1.0))
-            bits = int(np.float32(scale).view(np.uint32))
+            wx2, scale, frag_k = fwd.get(p["w"].data_ptr(), (0, 1.0, 0))
+            bits = int(np.float32(scale).view(np.uint32)) | (int(frag_k) << 32)
             ptrs.append([p["w"].data_ptr(), p["m"].data_ptr(), p["v"].data_ptr(), p["g"].data_ptr(), wx2, bits])
         self._adam_table = torch.tensor(ptrs, dtype=torch.int64, device=self.dev)
         self._adam_counts = torch.tensor([p["n"] for p in self.params], dtype=torch.int64, device=self.dev)

@@ -225,6 +225,36 @@ def join_f16x2(split):
 _TORCH_OF_CODE = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
 
 
+def compose_interconv_head(w1, b1, w2, b2):
+    """A linear 3x3 interconvN (w1 [3,3,Cin,Cm] HWIO, bias b1 [Cm]) followed by the linear 3x3 predict_flowN
+    (w2 [3,3,Cm,2], bias b2 [2]; flownet_sd.py:60-64, flownet2.py:74-77, :90-93: activation_fn=None on both, pad(.., 1)
+    in front of each) as ONE 5x5 convolution of the interconv's input:
+        pf(p) = b2 + sum_t w2[t] . ( b1 + sum_s w1[s] . x(p + t + s - 2) )          (x zero outside the image)
+    The reference zero-pads the interconv OUTPUT before the second convolution, so a tap t whose position p + t - 1
+    falls outside the image contributes nothing -- not the interconv evaluated there.  That only concerns the image's
+    outermost pixel ring; which taps drop out depends on the borders p touches: case = 3 * cy + cx with c = 0 (low
+    border), 1 (interior), 2 (high border) per axis.
+    Returns (w5 [9 cases][5,5,Cin,2], bias5 [9][2]) in float64; case 4 is the interior."""
+    w1, w2 = np.asarray(w1, np.float64), np.asarray(w2, np.float64)
+    b1 = np.zeros(w1.shape[3]) if b1 is None else np.asarray(b1, np.float64)
+    b2 = np.zeros(2) if b2 is None else np.asarray(b2, np.float64)
+    cin = w1.shape[2]
+    w5 = np.zeros((9, 5, 5, cin, 2))
+    bias5 = np.zeros((9, 2))
+    ok = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}   # taps of the second conv that stay inside the image, per border case
+    for cy in range(3):
+        for cx in range(3):
+            c = 3 * cy + cx
+            bias5[c] = b2
+            for ty in ok[cy]:
+                for tx in ok[cx]:
+                    bias5[c] += b1 @ w2[ty, tx]
+                    for sy in range(3):
+                        for sx in range(3):
+                            w5[c, ty + sy, tx + sx] += w1[sy, sx] @ w2[ty, tx]
+    return w5, bias5
+
+
 def to_fragment_order(wdev):
     """Split-fp16 packed weight on the device, layout 1 ([..., cout_pad, k] rows of 128-byte stages
     [hi g0 | lo g0 | ... | hi g3 | lo g3]) -> wgt_layout 2 of fn2_conv2d: per 32-row tile and stage four 1 KiB blocks

@@ -218,6 +218,15 @@ int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out
  * fn2_flow_head_ring and must be taken from there. */
 int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, float* pf, int n, int h, int w, int ring,
                        const float* up_w, const float* up_bias, const fn2_tensor* up_out, void* stream);
+/* The interior of a composed head in ONE launch, without the partials ever leaving the chip: for every pixel not on the
+ * outermost ring (all pixels when ring == 0)
+ *   pf[n,y,x,o] = bias[o] + sum_{u in 5x5} sum_ci w5[u][ci][o] x[n, y+uy-2, x+ux-2, ci]            (x zero outside the image)
+ * x: split-fp16 view whose channel run is whole 128-byte lines (cin_pad % 32 == 0, c0 + cin_pad <= cs); wgt: the 1x1
+ * matrix [64 rows (50 used: (uy*5+ux)*2+o)][cin_pad] in fn2_conv2d's wgt_layout 1 for a 64-row tile, split fp16, scaled by
+ * 1 / out_scale; pf dense fp32 [n,h,w,2].  A block forms the 50 partials of the 8 x 32 positions around a 4 x 28 output
+ * tile on the matrix cores, keeps them in LDS and sums the 25 shifted ones per output. */
+int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, float out_scale, const float* bias, float* pf,
+                   int ring, void* stream);
 /* Border ring of a composed head: pf[n,y,x,o] = bc[case][o] + sum_{u in 5x5} sum_ci wc[case][u][ci][o] x[n, y+uy-2, x+ux-2, ci]
  * for the pixels with y in {0, h-1} or x in {0, w-1}; case = 3*cy + cx with c = 0 / 1 / 2 for the low border / interior /
  * high border of that axis.  x: split-fp16 view; wc: fp32 [9][25][8*ceil(c/8)][2], zero on the pad channels; bc: fp32 [9][2]. */
@@ -295,6 +304,9 @@ int fn2_bias_grad(const fn2_tensor* g, float* db, void* stream);
  * forward and backward-data weight copies of the split-fp16 trainer, re-derived from the fp32 master every step
  * (scale = the power of two of the layer's descriptor, out_scale = 1 / scale). */
 int fn2_to_f16x2(void* dst, const float* src, const int32_t* map, int64_t n, float scale, void* stream);
+/* The same into fn2_conv2d's wgt_layout 2 (MFMA-fragment order; see fn2_conv_desc.wgt_layout): src is the packed
+ * [rows][k] matrix (rows % 32 == 0, k % 32 == 0, n = rows * k); only WHERE each 16-byte (hi / lo) chunk lands differs. */
+int fn2_to_f16x2_frag(void* dst, const float* src, const int32_t* map, int64_t n, float scale, int k, void* stream);
 /* Housekeeping of the train step on the caller's stream (what tf.gradients' accumulators and tf.zeros do in the
  * reference graph): zero a gradient buffer; dst += src (the correlation's two input gradients joining the towers'
  * gradient buffers, correlation.py:17-35); a dense copy of a channel slice of an fp32 NHWC buffer. */
@@ -308,7 +320,8 @@ int fn2_adam_step(float* w, float* m, float* v, const float* g, int64_t n, float
                   float eps, int step, float l2, float grad_scale, void* stream);
 /* The same update (tf.train.AdamOptimizer.apply_gradients, net.py:1290-1295) for n_tensors parameter tensors in
  * ONE launch.  table: device array of six 64-bit words per tensor: {float* w, float* m, float* v, const float* g,
- * void* w_f16x2, float scale (low 32 bits)} -- w_f16x2: the split-fp16 copy of w the convolutions read (same packed
+ * void* w_f16x2, float scale (low 32 bits) | int frag_k (high 32 bits: 0 = row-major copy, else the packed row length k of a
+ * wgt_layout-2 copy)} -- w_f16x2: the split-fp16 copy of w the convolutions read (same packed
  * geometry), rewritten as w * scale by the same pass, or NULL; every pointer 16-byte aligned.  counts / l2: device
  * arrays of element counts (int64) and L2 coefficients (0 where the reference does not regularise). */
 int fn2_adam_step_multi(const void* table, const int64_t* counts, const float* l2, int n_tensors, float lr, float beta1,

@@ -544,3 +544,41 @@ def test_conv_fragment_order_weights(kind, k, s, p, cin, cout, N, H, W, out_f32)
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
     base = run_conv(x, w, b, kind, k, s, p, True, "f16x2", out_f32=out_f32, cout_off=8, extra_out=8)
     np.testing.assert_allclose(got, base, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,cin", [(2, 37, 61, 82), (1, 8, 56, 162), (3, 5, 9, 32)])
+def test_flow_head5_fused(N, H, W, cin):
+    """fn2_flow_head5: a 5x5 two-output convolution (the composed interconvN + predict_flowN head) with the 50 partials
+    of a position formed on the matrix cores and summed from LDS -- against the oracle's conv2d with zero padding 2
+    (ring = 0), and with ring = 1 the outermost pixel ring left exactly as pf held it."""
+    from src import _hip, weights as Wt
+    lib = _hip.lib()
+    x = rnd((N, H, W, cin), 80)
+    w5 = rnd((5, 5, cin, 2), 81, (1.0 / (25 * cin)) ** 0.5)
+    bias = np.array([0.3, -0.7], np.float32)
+    want = refnn.conv2d(x, w5, bias, stride=1, padding=2)
+    cs = (cin + 31) // 32 * 32
+    xp = np.zeros((N, H, W, cs), np.float32)
+    xp[..., :cin] = x
+    xin = _to_dev(xp, "f16x2")
+    plan = _hip.conv_plan(3, cs, 50)
+    assert plan.layout == 1 and plan.cout_tile == 64
+    w1x1 = np.ascontiguousarray(w5.transpose(2, 0, 1, 3)).reshape(1, 1, cin, 50)
+    packed, cin_pad, cout_pad, kpad = Wt.pack_conv(w1x1, plan.cout_tile, plan.kstep_elems, cs, plan.layout)
+    k2 = int(np.floor(np.log2(1024.0 / np.abs(packed).max())))
+    wdev = Wt.packed_to_device(packed * 2.0 ** k2, plan.wgt_dtype, "cuda")
+    bd = torch.from_numpy(bias).cuda()
+    v = _hip.view(xin, cin, 0, 3)
+    for ring in (0, 1):
+        pf0 = rnd((N, H, W, 2), 82)
+        pf = torch.from_numpy(pf0).cuda()
+        _hip.check(lib.fn2_flow_head5(C.byref(v), wdev.data_ptr(), cin_pad, kpad, C.c_float(2.0 ** -k2), bd.data_ptr(),
+                                      pf.data_ptr(), ring, _hip.stream_ptr()))
+        torch.cuda.synchronize()
+        exp = want.copy()
+        if ring:
+            m = np.zeros((H, W), bool)
+            m[0], m[-1], m[:, 0], m[:, -1] = True, True, True, True
+            exp[:, m] = pf0[:, m]
+        np.testing.assert_allclose(pf.cpu().numpy(), exp, rtol=2e-5, atol=2e-5)

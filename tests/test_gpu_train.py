@@ -639,3 +639,29 @@ def test_loss_surface_through_the_library():
              for l in (6, 5, 4, 3, 2)}
     want, _ = refm.multiscale_loss(gt_nonan := np.nan_to_num(gt), {k: v.cpu().numpy() for k, v in preds.items()}, None)
     assert float(losses.multiscale_loss(gt_nonan, preds)) == pytest.approx(want, rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_fragment_order_weight_copies_in_the_trainer(monkeypatch):
+    """FN2_TRAIN_WREG=1: forward and input-gradient convolutions read weight copies in MFMA-fragment order
+    (fn2_to_f16x2_frag, Adam's fragment-order store); same loss, gradients and weights after two Adam steps as the
+    row-major copies (the arithmetic is identical; only the tile / split choice of a few launches differs)."""
+    from src import weights as W
+    from src.trainer import FlowNetSTrainer
+    wts = W.init_weights("FlowNetS", 11)
+    a, b, gt = data(2, 128, 192, 5)
+    base = FlowNetSTrainer(wts, 2, 128, 192, dtype="f16x2")
+    monkeypatch.setenv("FN2_TRAIN_WREG", "1")
+    frag = FlowNetSTrainer(wts, 2, 128, 192, dtype="f16x2")
+    assert any(rec.get("frag") for rec in frag.eng.layers) and any(g[4] for g in frag.gathers)
+    for step in range(2):
+        lb = float(base.forward_backward(a, b, gt).item())
+        lf = float(frag.forward_backward(a, b, gt).item())
+        assert abs(lb - lf) <= 1e-6 * abs(lb)
+        for pb, pf in zip(base.params, frag.params):
+            assert float((pb["g"] - pf["g"]).abs().max()) <= 1e-5 * float(pb["g"].abs().max()) + 1e-12, pb["name"]
+        base.apply_gradients()
+        frag.apply_gradients()
+    for pb, pf in zip(base.params, frag.params):
+        d = (pb["w"] - pf["w"]).abs()
+        assert float((d > 1e-6).float().mean()) < 0.01 and float(d.max()) <= 4.1e-4, pb["name"]
