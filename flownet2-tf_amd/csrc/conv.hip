@@ -1328,7 +1328,7 @@ int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, fl
 }
 
 int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, float out_scale, const float* bias, float* pf,
-                   int ring, void* stream) {
+                   int ring, const float* ring_w, const float* ring_b, void* stream) {
   int rc = check_view(x, "flow_head5 input");
   if (rc) return rc;
   FN2_REQUIRE(wgt && pf, "flow_head5: null pointer");
@@ -1357,7 +1357,15 @@ int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, 
   a.out_scale = out_scale == 0.f ? 1.f : out_scale;
   a.in_bytes = (int)in_bytes;
   a.dbg = 0;                             // (XCD-aware order: each XCD walks a contiguous run of tiles, halos stay in its L2)
-  return launch_head5(a, (int)blocks, (hipStream_t)stream);
+  a.h5_tiles = (int)blocks;
+  long total = blocks;
+  if (ring && ring_w != nullptr) {       // the ring as extra blocks of the same launch, 16 ring pixels each
+    FN2_REQUIRE(ring_b != nullptr, "flow_head5: ring_w without ring_b");
+    a.h5_wc = ring_w; a.h5_bc = ring_b; a.h5_groups = (x->c + 7) / 8;
+    FN2_REQUIRE(x->c0 + a.h5_groups * 8 <= x->cs, "flow_head5: the last 8-channel group reaches past the buffer");
+    total += cdiv((long)x->n * (2 * x->w + 2 * (x->h - 2)), 16);
+  }
+  return launch_head5(a, (int)total, (hipStream_t)stream);
 }
 
 int fn2_flow_head_ring(const fn2_tensor* x, const float* wc, const float* bc, float* pf, void* stream) {

@@ -73,6 +73,53 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
                :: "s"(la), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// Border ring of a composed head (fn2_flow_head_ring, conv.hip head_ring_kernel) as extra blocks of the HEAD5 launch:
+// block `rb` of the ring part takes 16 ring pixels, a wave four of them one after the other (wave per pixel: lanes stride
+// the (tap, 8-channel group) items, shuffle reduction).
+__device__ __forceinline__ void h5_ring_block(const ConvArgs& p, int rb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = p.OH, W = p.OW, ring = 2 * W + 2 * (H - 2);
+  const int nitems = 25 * p.h5_groups;
+  const size_t case_stride = (size_t)nitems * 16;
+  const x2_t* in = reinterpret_cast<const x2_t*>(p.in);
+  float* pf = reinterpret_cast<float*>(p.out);
+  for (int k = 0; k < 4; ++k) {
+    const long m = (long)rb * 16 + wave * 4 + k;
+    if (m >= (long)p.N * ring) return;
+    const int n = (int)(m / ring), r = (int)(m - (long)n * ring);
+    int y, x;
+    if (r < W) { y = 0; x = r; }
+    else if (r < 2 * W) { y = H - 1; x = r - W; }
+    else { const int q = r - 2 * W; y = 1 + (q >> 1); x = (q & 1) ? W - 1 : 0; }
+    const int cy = y == 0 ? 0 : (y == H - 1 ? 2 : 1), cx = x == 0 ? 0 : (x == W - 1 ? 2 : 1);
+    const int cs = 3 * cy + cx;
+    const float* w = p.h5_wc + (size_t)cs * case_stride;
+    float a0 = 0.f, a1 = 0.f;
+    for (int q = lane; q < nitems; q += 64) {
+      const int tap = q / p.h5_groups, gi = q - tap * p.h5_groups;
+      const int ky = tap / 5, kx = tap - ky * 5;
+      const int iy = y + ky - 2, ix = x + kx - 2;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const uint4* src = reinterpret_cast<const uint4*>(in + (((size_t)n * H + iy) * W + ix) * p.in_cs + p.in_c0 + gi * 8);
+      float xv[8];
+      join8(src[0], src[1], xv);
+      const float* u = w + (size_t)q * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0 += xv[j] * u[2 * j];
+        a1 += xv[j] * u[2 * j + 1];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64);
+      a1 += __shfl_xor(a1, off, 64);
+    }
+    if (lane == 0)
+      *reinterpret_cast<float2*>(pf + (((size_t)n * H + y) * W + x) * 2) = make_float2(a0 + p.h5_bc[2 * cs], a1 + p.h5_bc[2 * cs + 1]);
+  }
+}
+
 // HEAD5 epilogue: word w of the partial-sum table T, which spans the two stage buffers (two LDS objects of `half` bytes)
 __device__ __forceinline__ float* h5_t(uint4* a, uint4* b, int half, int w) {
   const int byte = w * 4;
@@ -140,6 +187,12 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   __shared__ uint4 lds1_all[(kDeep || WREG) ? 1 : KG * ROWS * 8];
   __shared__ uint4 lds2_own[(STAGES == 3 && !WREG) ? ROWS * 8 : 1];
 
+  if constexpr (HEAD5) {
+    if ((int)blockIdx.x >= p.h5_tiles) {  // the ring part of the grid (block-uniform)
+      h5_ring_block(p, (int)blockIdx.x - p.h5_tiles);
+      return;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = KG > 1 ? wave_all >> 2 : 0;   // K group of this wave
@@ -171,7 +224,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   // XCD share the input tile, then move to the adjacent one (halo rows still in that XCD's L2).
   int bx = blockIdx.x, by = blockIdx.y;
   if (!(p.dbg & 4)) {
-    const int NT = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int NT = HEAD5 ? p.h5_tiles : gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;  // (HEAD5: the tile part of the grid)
     const int xcd = L & 7, chunk = NT >> 3, rem = NT & 7;
     const int Lp = xcd * chunk + min(xcd, rem) + (L >> 3);
     if (p.wmajor) {

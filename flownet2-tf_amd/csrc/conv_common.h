@@ -26,7 +26,10 @@ struct ConvArgs {
   int bp64;     // LDS-DMA kernel: half-width pixel tiles (128x64 / 64x128 / 32x128), see wants_bp64 in conv.hip
   int KH_KW_hint;  // kind 2 (row-run stems): the real kernel width KW (KW itself is 1 there: a kernel row is one "tap"); else 0
   int kg;       // LDS-DMA kernel, 128 x 64 tiles: K groups per block (1, 2 or 3; conv2.hip), see build_args in conv.hip
-  int h5_tx, h5_ty, h5_ring;  // composed 5x5 flow head (conv2.hip, HEAD5): tiles per image row / column, ring pixels pre-written
+  int h5_tx, h5_ty, h5_ring;  // composed 5x5 flow head (conv2.hip, HEAD5): tiles per image row / column, ring pixels handled apart
+  int h5_tiles, h5_groups;    // ... blocks [h5_tiles, gridDim.x) compute the border ring from these (nullptr: no ring blocks):
+  const float* h5_wc;         //     fp32 [9 cases][25 taps][8 h5_groups][2]
+  const float* h5_bc;         //     fp32 [9][2]
   int wfrag;    // 1: the weight is stored in MFMA-fragment order (wgt_layout 2) and loaded straight into registers (conv2.hip, WREG)
   int accum;    // 1: out += result (fp32 outputs; gradient accumulation into shared buffers)
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0

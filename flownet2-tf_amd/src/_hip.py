@@ -75,7 +75,7 @@ PROTOTYPES = {
     "fn2_upsample_flow": (_i, [_p, _p, _p, _tp, _i, _i, _i, _p]),
     "fn2_flow_head_tail": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _tp, _p]),
     "fn2_flow_head_ring": (_i, [_tp, _p, _p, _p, _p]),
-    "fn2_flow_head5": (_i, [_tp, _p, _i, _i, _f, _p, _p, _i, _p]),
+    "fn2_flow_head5": (_i, [_tp, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p]),
     "fn2_u8_to_f32_lut": (_i, [_p, _p, _p, C.c_int64, _p]),
     "fn2_pack_pair": (_i, [_p, _p, _tp, _i, _p]),
     "fn2_pack_image": (_i, [_p, _i, _tp, _i, _i, _p]),

@@ -453,8 +453,6 @@ class Engine:
         bcd = W.to_device(bias5.astype(np.float32), torch.float32, self.device)
         vin = self._v(sbuf, sc, sc0)
         self.keep += [wcd, bcd, vin]
-        self._op(f"{scope}/{pf_name}/ring", self.lib.fn2_flow_head_ring, C.byref(vin), _hip.ptr(wcd), _hip.ptr(bcd), _hip.ptr(pf),
-                 kernel="flow_head_ring")
         # ---- interior: 1x1 GEMM with 50 outputs (tap * 2 + o), then the 25-tap tail
         w1x1 = np.ascontiguousarray(w5[4].transpose(2, 0, 1, 3)).reshape(1, 1, sc, 50).astype(np.float32)
         packed, cin_pad, cout_pad, kpad = W.pack_conv(w1x1, plan.cout_tile, plan.kstep_elems, cin_line, plan.layout)
@@ -472,11 +470,13 @@ class Engine:
             vx = self._v(sbuf, sc, sc0)
             self.keep += [wdev, b5, vx]
             self._op(f"{scope}/{ic_name}+{pf_name}", self.lib.fn2_flow_head5, C.byref(vx), _hip.ptr(wdev), cin_pad, kpad,
-                     C.c_float(out_scale), _hip.ptr(b5), _hip.ptr(pf), 1,
+                     C.c_float(out_scale), _hip.ptr(b5), _hip.ptr(pf), 1, _hip.ptr(wcd), _hip.ptr(bcd),
                      kernel="conv_igemm2_kernel<fn2::x2_t, float, 1, 4, 2, 2, 2, 1, false, false, false, true>")
             self.layer_flops.append((f"{scope}/{ic_name}+{pf_name}", 2.0 * n * h * wd * 9 * (sc * cm + cm * 2)))
             self.layer_io_bytes.append((f"{scope}/{ic_name}+{pf_name}", float(n * h * wd * (sc * 4 + 2 * 4) + 9 * (sc * cm + 2 * cm) * 4)))
             return 1
+        self._op(f"{scope}/{pf_name}/ring", self.lib.fn2_flow_head_ring, C.byref(vin), _hip.ptr(wcd), _hip.ptr(bcd), _hip.ptr(pf),
+                 kernel="flow_head_ring")
         if self._head_t is None:
             self._head_t = {}
         key = (self._branch, 64)

@@ -224,9 +224,11 @@ int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, fl
  * x: split-fp16 view whose channel run is whole 128-byte lines (cin_pad % 32 == 0, c0 + cin_pad <= cs); wgt: the 1x1
  * matrix [64 rows (50 used: (uy*5+ux)*2+o)][cin_pad] in fn2_conv2d's wgt_layout 1 for a 64-row tile, split fp16, scaled by
  * 1 / out_scale; pf dense fp32 [n,h,w,2].  A block forms the 50 partials of the 8 x 32 positions around a 4 x 28 output
- * tile on the matrix cores, keeps them in LDS and sums the 25 shifted ones per output. */
+ * tile on the matrix cores, keeps them in LDS and sums the 25 shifted ones per output.
+ * ring != 0 with ring_w / ring_b (fn2_flow_head_ring's wc / bc): extra blocks of the same launch compute the ring pixels;
+ * with ring_w == NULL they are left as they are (written by fn2_flow_head_ring, or not needed). */
 int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, float out_scale, const float* bias, float* pf,
-                   int ring, void* stream);
+                   int ring, const float* ring_w, const float* ring_b, void* stream);
 /* Border ring of a composed head: pf[n,y,x,o] = bc[case][o] + sum_{u in 5x5} sum_ci wc[case][u][ci][o] x[n, y+uy-2, x+ux-2, ci]
  * for the pixels with y in {0, h-1} or x in {0, w-1}; case = 3*cy + cx with c = 0 / 1 / 2 for the low border / interior /
  * high border of that axis.  x: split-fp16 view; wc: fp32 [9][25][8*ceil(c/8)][2], zero on the pad channels; bc: fp32 [9][2]. */

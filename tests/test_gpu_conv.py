@@ -574,7 +574,7 @@ def test_flow_head5_fused(N, H, W, cin):
         pf0 = rnd((N, H, W, 2), 82)
         pf = torch.from_numpy(pf0).cuda()
         _hip.check(lib.fn2_flow_head5(C.byref(v), wdev.data_ptr(), cin_pad, kpad, C.c_float(2.0 ** -k2), bd.data_ptr(),
-                                      pf.data_ptr(), ring, _hip.stream_ptr()))
+                                      pf.data_ptr(), ring, None, None, _hip.stream_ptr()))
         torch.cuda.synchronize()
         exp = want.copy()
         if ring:
@@ -582,3 +582,25 @@ def test_flow_head5_fused(N, H, W, cin):
             m[0], m[-1], m[:, 0], m[:, -1] = True, True, True, True
             exp[:, m] = pf0[:, m]
         np.testing.assert_allclose(pf.cpu().numpy(), exp, rtol=2e-5, atol=2e-5)
+    # the ring as extra blocks of the launch: nine weight sets (here: case c scaled by 1 + c / 10), one bias pair per case
+    groups = (cin + 7) // 8
+    wc = np.zeros((9, 25, groups * 8, 2), np.float32)
+    bc = np.zeros((9, 2), np.float32)
+    for c in range(9):
+        wc[c, :, :cin] = (w5 * (1.0 + c / 10.0)).reshape(25, cin, 2)
+        bc[c] = bias + c
+    wcd, bcd = torch.from_numpy(wc).cuda(), torch.from_numpy(bc).cuda()
+    pf = torch.zeros((N, H, W, 2), dtype=torch.float32, device="cuda")
+    _hip.check(lib.fn2_flow_head5(C.byref(v), wdev.data_ptr(), cin_pad, kpad, C.c_float(2.0 ** -k2), bd.data_ptr(),
+                                  pf.data_ptr(), 1, wcd.data_ptr(), bcd.data_ptr(), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    exp = want.copy()
+    lin = want - bias
+    for y in range(H):
+        for xx in range(W):
+            cy = 0 if y == 0 else (2 if y == H - 1 else 1)
+            cx = 0 if xx == 0 else (2 if xx == W - 1 else 1)
+            c = 3 * cy + cx
+            if c != 4:
+                exp[:, y, xx] = lin[:, y, xx] * (1.0 + c / 10.0) + bias + c
+    np.testing.assert_allclose(pf.cpu().numpy(), exp, rtol=3e-5, atol=3e-5)
