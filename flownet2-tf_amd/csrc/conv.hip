@@ -1356,7 +1356,7 @@ int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, 
   a.kg = 1; a.splitk = 1; a.kper = a.ksteps; a.ws = nullptr; a.ws_cs = 4;
   a.out_scale = out_scale == 0.f ? 1.f : out_scale;
   a.in_bytes = (int)in_bytes;
-  a.dbg = 0;                             // (XCD-aware order: each XCD walks a contiguous run of tiles, halos stay in its L2)
+  { const char* e = getenv("FN2_H5_DBG"); a.dbg = e ? atoi(e) : 0; }   // 0: XCD-aware tile order; ablation bits 2 / 8 / 4 (timing only)
   a.h5_tiles = (int)blocks;
   long total = blocks;
   if (ring && ring_w != nullptr) {       // the ring as extra blocks of the same launch, 16 ring pixels each

@@ -650,6 +650,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   }
 
   if constexpr (HEAD5) {
+    if (p.dbg & 2) return;  // (ablation: K loop only)
     // partials -> LDS as T[position][52] (50 used: (uy * 5 + ux) * 2 + o), then the 25-tap sums.  The two-stage loop ended
     // with a barrier, so the stage buffers (2 x (64 + 256) x 128 B) are free.
     constexpr int TS = 52;
@@ -668,6 +669,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
                             acc[tc][tp][4 * q + 2] * p.out_scale, acc[tc][tp][4 * q + 3] * p.out_scale);
       }
     __syncthreads();
+    if (p.dbg & 8) return;  // (ablation: no gather)
     const int tx = bx % p.h5_tx, tyn = bx / p.h5_tx;
     const int n = tyn / p.h5_ty, ty = tyn - n * p.h5_ty;
     float* pf = reinterpret_cast<float*>(p.out);

@@ -164,7 +164,13 @@ typedef struct {
   int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */
   int32_t cout_pad;    /* rows per phase in the packed weight */
   int32_t kpad;        /* elements per packed row */
-  int32_t wgt_layout;  /* row order of the packed weight: fn2_conv_plan.layout */
+  int32_t wgt_layout;  /* row order of the packed weight: fn2_conv_plan.layout -- or 2 where the plan says 1, the input is
+                          split fp16 and the cout tile is 128 (64): layout 1's matrix re-tiled into MFMA-FRAGMENT order,
+                          per 32-row tile t and 128-byte stage s four 1 KiB blocks f = 2 q + part at byte
+                          ((t * kpad / 32 + s) * 4 + f) * 1024, lane 32 h + r of a block = the 16-byte chunk
+                          4 q + 2 h + part of row 32 t + r (part 0 = hi, 1 = lo halves of an 8-channel group).  The launch
+                          then loads the weight operand straight into registers (conv2.hip, WREG); the same values,
+                          the same result up to fp32 summation order.  fn2_to_f16x2_frag writes this layout. */
   int32_t accumulate;  /* 1: out += result (fp32 outputs only): gradient accumulation */
   float out_scale;     /* accumulator scale applied before the bias (0 = 1): lets the packer store
                           2^k-scaled weights so that split-fp16 lo parts stay normal fp16 numbers */
