@@ -946,8 +946,9 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   rc = check_view(&d->out, "conv2d output");
   if (rc) return rc;
   FN2_REQUIRE(d->wgt, "conv2d: null weights");
-  FN2_REQUIRE(d->kind >= 0 && d->kind <= 3,
-              "conv2d: kind must be 0 (conv), 1 (deconv k4 s2 crop 1), 2 (stem row-run conv) or 3 (transpose of a stride-2 conv)");
+  FN2_REQUIRE((d->kind >= 0 && d->kind <= 3) || d->kind == 5,
+              "conv2d: kind must be 0 (conv), 1 (deconv k4 s2 crop 1), 2 (stem row-run conv), 3 (transpose of a stride-2 conv) "
+              "or 5 (deconv k4 s2 crop 1, column phases merged)");
   FN2_REQUIRE(d->in.n == d->out.n, "conv2d: batch mismatch");
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cin_pad >= d->in.c, "conv2d: cin_pad must be a multiple of 8 >= Cin");
   FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: input channel stride/offset must be multiples of 8");
@@ -979,6 +980,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   ConvArgs& a = *out;
   a.KH_KW_hint = 0;
   a.wfrag = wfrag ? 1 : 0;   // (2 = the 3-slot ring form, chosen below)
+  a.merged = d->kind == 5 ? 1 : 0;
   a.in = d->in.data; a.wgt = d->wgt; a.bias = d->bias; a.out = d->out.data;
   a.N = d->in.n; a.H = d->in.h; a.W = d->in.w; a.in_cs = d->in.cs; a.in_c0 = d->in.c0;
   a.cin_chunks = d->cin_pad / CH;
@@ -1008,6 +1010,20 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
     FN2_REQUIRE(d->out.h == a.OH && d->out.w == a.OW, "stem conv: output spatial size %dx%d != expected %dx%d",
                 d->out.h, d->out.w, a.OH, a.OW);
     a.deconv = 0; a.ph_pad0 = a.ph_pad1 = 0;
+  } else if (d->kind == 5) {
+    // the same transposed convolution as kind 1 for 16 / 32 output channels on split fp16 (the fusion net's fuse_deconv0 /
+    // fuse_deconv1, flownet2.py:66-84): blockIdx.z = output row phase a, both column phases in one block as a 2 x 3-tap
+    // convolution with 2 Cout packed rows (weights.pack_deconv_merged)
+    FN2_REQUIRE(d->kh == 4 && d->kw == 4 && d->stride == 2, "deconv (kind 5): only k=4 s=2 crop 1");
+    FN2_REQUIRE((d->out.c == 16 || d->out.c == 32) && d->in.dtype == FN2_F16X2 && d->wgt_layout == 1 && d->cout_pad == 2 * d->out.c,
+                "deconv (kind 5): 16 or 32 output channels, split-fp16 input, cout_pad = 2 Cout");
+    FN2_REQUIRE(d->in.w % 128 == 0, "deconv (kind 5): input width must be a multiple of 128 (halo kernel tiles)");
+    a.KH = 2; a.KW = 3; a.stride = 1; a.pad = 0;
+    a.OH = d->in.h; a.OW = d->in.w;
+    FN2_REQUIRE(d->out.h == 2 * d->in.h && d->out.w == 2 * d->in.w, "deconv: output must be 2H x 2W");
+    a.deconv = 1;
+    a.ph_pad0 = 1; a.ph_pad1 = 0;
+    phases = 2;
   } else if (d->kind == 1) {
     FN2_REQUIRE(d->kh == 4 && d->kw == 4 && d->stride == 2, "deconv: only k=4 s=2 crop 1 (flownet_s.py:53-63)");
     // bias: nullptr inside the refinement scopes (biases_initializer=None, flownet_s.py:53); the FlowNet2 fusion
@@ -1149,6 +1165,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
 // Preferred split-K factor: fill >= ~2 blocks per CU on layers whose output grid is small
 // (the 6x8 .. 24x32 resolution layers: weight-bandwidth bound, SURVEY.md section 7 "hard parts").
 static int preferred_split(const ConvArgs& a, int tile, int phases) {
+  if (a.merged) return 1;  // kind 5 runs on the halo kernel: no K split
   const int bp = tile == 128 ? (a.bp64 ? 64 : 128) : (a.bp64 ? 128 : 256);
   const long blocks = (long)cdiv(a.M, bp) * (a.cout_pad / tile) * phases;
   const char* e_min = getenv("FN2_SPLIT_MINBLOCKS");  // tuning knob: grids from this many blocks up take no split-K

@@ -893,7 +893,10 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
   const T* wgt = reinterpret_cast<const T*>(p.wgt);
   const int phase = blockIdx.z;
   const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
-  if (p.deconv) {
+  if (p.merged) {  // kind 5: the two column phases of output row 2y + phase in one block (columns x - 1 .. x + 1 of the input)
+    pad_y = phase ? p.ph_pad1 : p.ph_pad0; pad_x = 1; oy_off = phase; ox_off = 0; osc = 2;
+    wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
+  } else if (p.deconv) {
     const int a = phase >> 1, b = phase & 1;
     pad_y = a ? p.ph_pad1 : p.ph_pad0; pad_x = b ? p.ph_pad1 : p.ph_pad0; oy_off = a; ox_off = b; osc = 2;
     wgt += (size_t)phase * p.cout_pad * (wrow_bytes / ESZ);
@@ -1020,14 +1023,16 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
   float* const etl = reinterpret_cast<float*>(sizeof(ldsA) >= 4 * 32 * ERS * 4 ? &ldsA[0][0] : &ldsB[0][0]) + wave * (32 * ERS);
 #pragma unroll
   for (int tc = 0; tc < TCN; ++tc) {
-    const int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
+    int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
+    int bsel = 0;   // merged (kind 5): packed row b Cout + co -> column phase b = output pixel 2 x + b, channel co
+    if (p.merged) { bsel = cout_base / p.Cout; cout_base -= bsel * p.Cout; if (bsel > 1) continue; }
     float bias[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) bias[q] = (p.bias != nullptr && cout_base + q < p.Cout) ? p.bias[cout_base + q] : 0.f;
 #pragma unroll
     for (int tp = 0; tp < TPN; ++tp) {
       const int ox = tox + wp * TPN * 32 + tp * 32 + fr;
-      OutT* po = out + (((size_t)tn * p.out_H + (toy * osc + oy_off)) * p.out_W + (ox * osc + ox_off)) * p.out_cs +
+      OutT* po = out + (((size_t)tn * p.out_H + (toy * osc + oy_off)) * p.out_W + (ox * osc + ox_off + bsel)) * p.out_cs +
                  p.out_c0 + cout_base;
       float v[16];
 #pragma unroll
@@ -1037,7 +1042,7 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = leaky(v[q]);
       }
-      if (sizeof(OutT) == 4 && vec16 && c0 + wc * TCN * 32 + tc * 32 + 32 <= p.Cout && !(p.dbg & 4194304)) {
+      if (sizeof(OutT) == 4 && vec16 && !p.merged && c0 + wc * TCN * 32 + tc * 32 + 32 <= p.Cout && !(p.dbg & 4194304)) {
         // 128-byte runs through a wave-private LDS tile (the loop's last barrier has passed), as in conv_rowrun_kernel
         store16<OutT>(reinterpret_cast<OutT*>(etl + fr * ERS + fh * 16), v);
         const int rr = lane >> 3, ch = lane & 7;
@@ -1403,7 +1408,7 @@ static bool launch_stem(const ConvArgs& a, int tile, int phases, hipStream_t s) 
 // stride-1 split-fp16 layers whose tiles stay inside image rows run the halo kernel; FN2_CONV_DBG bit 2048 = off (A/B)
 template <typename OutT>
 static bool launch_halo(const ConvArgs& a, int tile, int phases, hipStream_t s) {
-  if ((a.dbg & 2048) || a.stride != 1 || a.splitk != 1 || a.kg != 1 || !a.bp64 || a.wfrag || (a.KW != 2 && a.KW != 3)) return false;
+  if (((a.dbg & 2048) && !a.merged) || a.stride != 1 || a.splitk != 1 || a.kg != 1 || !a.bp64 || a.wfrag || (a.KW != 2 && a.KW != 3)) return false;
   if (a.deconv && (a.kh_ph[0] != a.KH || a.kh_ph[1] != a.KH || a.kw_ph[0] != a.KW || a.kw_ph[1] != a.KW)) return false;  // trimmed phases: conv_igemm2_kernel
   // one-round 128 x 64 grids (384..512 blocks) keep the 3-slot ring: two stages of DMA in flight beat the smaller
   // stream there (conv3_1 at batch 4: ring 0.196 ms per 3 launches, halo 0.213)
@@ -1535,9 +1540,11 @@ int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, i
     if (launch_rowrun<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_rowrun"); return FN2_OK; }
     if (launch_stem<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_stem"); return FN2_OK; }
     if (launch_halo<x2_t>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_halo"); return FN2_OK; }
+    if (a.merged) return fail(FN2_ERR_UNSUPPORTED, "conv2d kind 5: needs the halo kernel (input width a multiple of 128, no split-K)");
     return launch2<x2_t, x2_t>(a, tile, phases, s);
   }
   if (launch_halo<float>(a, tile, phases, s)) { FN2_CHECK_LAUNCH("conv_halo"); return FN2_OK; }
+  if (a.merged) return fail(FN2_ERR_UNSUPPORTED, "conv2d kind 5: needs the halo kernel (input width a multiple of 128, no split-K)");
   return launch2<x2_t, float>(a, tile, phases, s);
 }
 

@@ -22,6 +22,7 @@ struct ConvArgs {
   int ph_pad0, ph_pad1;  // tap origin of phase a = 0 / 1: input row = m - ph_pad + t
   int kh_ph[2], kw_ph[2];  // taps a phase really has (rows: phase >> 1, columns: phase & 1); the packed weight keeps KH x KW slots per phase.
                            // kind 3 (transpose of a k x k stride-2 conv): 9 of 16 slots (k = 3), 25 of 36 (k = 5) are non-zero
+  int merged;   // kind 5 (halo kernel): blockIdx.z = output row phase a, packed row b Cout + co = column phase b, channel co
   int wmajor;   // LDS-DMA kernel: XCD bands run over the pixel tiles of ONE cout tile (weight-streaming layers), see conv.hip
   int bp64;     // LDS-DMA kernel: half-width pixel tiles (128x64 / 64x128 / 32x128), see wants_bp64 in conv.hip
   int KH_KW_hint;  // kind 2 (row-run stems): the real kernel width KW (KW itself is 1 there: a kernel row is one "tap"); else 0

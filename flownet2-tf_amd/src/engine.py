@@ -284,8 +284,16 @@ class Engine:
             cin_pad = cin_line
         plan = _hip.conv_plan(in_code, cin_pad, cout)
         tile, layout = plan.cout_tile, plan.layout
+        # transposed convs with 16 outputs on wide maps (the fusion net's fuse_deconv0): both column phases of an output row
+        # in one block (fn2_conv2d kind 5): 164.6 -> 116.9 us.  With 32 outputs (fuse_deconv1) the four-phase form has no
+        # half-empty tile to begin with and the third tap slot only adds work: 39.8 -> 50.6 us, not taken.
+        # Inference engines only; FN2_DECONV_MERGED=0: off (A/B)
+        merged = (kind != "conv" and self.compose_heads and cout == 16 and in_code == _hip.FN2_F16X2 and layout == 1
+                  and tile == 32 and sbuf.shape[2] % 128 == 0 and bool(int(os.environ.get("FN2_DECONV_MERGED", "1"))))
         if kind == "conv":
             packed, cin_pad, cout_pad, kpad = W.pack_conv(self._w(wname), tile, plan.kstep_elems, cin_pad, layout)
+        elif merged:
+            packed, cin_pad, cout_pad, kpad = W.pack_deconv_merged(self._w(wname), tile, plan.kstep_elems, cin_pad, layout)
         else:
             packed, cin_pad, cout_pad, kpad = W.pack_deconv(self._w(wname), tile, plan.kstep_elems, cin_pad, layout)
         bias = self._bias(scope, name, kind, cout)  # transposed convs: only where the graph declares one (fusion net)
@@ -304,7 +312,7 @@ class Engine:
         d.out = self._v(dbuf, dc, dc0)
         d.wgt = wdev.data_ptr()
         d.bias = bias.data_ptr() if bias is not None else None
-        d.kind = 0 if kind == "conv" else 1
+        d.kind = 0 if kind == "conv" else (5 if merged else 1)
         d.kh = d.kw = k
         d.stride, d.pad = stride, pad
         d.act = _hip.ACT_LEAKY if act else _hip.ACT_NONE

@@ -166,6 +166,29 @@ def pack_deconv(w_hwoi, cout_tile, kstep_elems, cin_pad=None, layout=0, dtype=np
     return out, cin_pad, cout_pad, kpad
 
 
+def pack_deconv_merged(w_hwoi, cout_tile, kstep_elems, cin_pad, layout=1, dtype=np.float32):
+    """[4,4,Cout,Cin] (HW-O-I), Cout in (16, 32) -> [2 row phases][2 Cout][6 cin_pad]: fn2_conv2d kind 5.  Row phase a holds
+    both column phases b of the output row 2y + a as ONE 2 x 3-tap stride-1 convolution with 2 Cout output rows
+    (row b Cout + co -> output pixel (2y + a, 2x + b), channel co): tap (ty, kx3) reads input (y - 1 + a + ty, x - 1 + kx3);
+    column phase b uses kx3 = b + tx, tx in {0, 1}, with the weight of (ky, kx) = (3 - a - 2 ty, 3 - b - 2 tx) and zeros in
+    its third slot.  Half the passes over the input of the four-phase form, and for Cout = 16 no half-empty 32-row tile."""
+    kh, kw, cout, cin = w_hwoi.shape
+    assert kh == 4 and kw == 4 and cout in (16, 32) and cin_pad >= cin and cin_pad % 8 == 0 and cout_tile == 32
+    cout_pad = 2 * cout
+    kpad = _round_up(6 * cin_pad, kstep_elems)
+    out = np.zeros((2, cout_pad, kpad), dtype)
+    for a in range(2):
+        p = np.zeros((cout_pad, 6, cin_pad), dtype)
+        for b in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    p[b * cout:(b + 1) * cout, ty * 3 + b + tx, :cin] = w_hwoi[3 - a - 2 * ty, 3 - b - 2 * tx]
+        ph = np.zeros((cout_pad, kpad), dtype)
+        ph[:, :6 * cin_pad] = p.reshape(cout_pad, -1)
+        out[a] = _permute_rows64(ph) if layout == 1 else ph
+    return out, cin_pad, cout_pad, kpad
+
+
 def pack_conv_transpose_s2(w_hwio, p, cout_tile, kstep_elems, cin_pad, layout, dtype=np.float32):
     """Weights of fn2_conv2d kind 3 -- the input gradient of a stride-2 convolution with kernel k, pad p and
     forward weight w_hwio [k,k,Ci,Co]: a transposed convolution whose "input channels" are Co and "output

@@ -150,6 +150,11 @@ int fn2_resize_bilinear_f32(const float* in, float* out, int n, int in_h, int in
  *   kind 3: the transposed convolution that is the input-gradient of a stride-2 kind-0 layer (kh = kw = k,
  *           pad = p of THAT layer): four phases of ceil(k/2)^2 taps; packed weight [4][cout_pad][T*T*cin_pad]
  *           with tap (ty,tx) of phase (a,b) = W[ky = a+p-2*lo_a-2*ty][kx likewise], lo_a = ceil((a+p-k+1)/2).
+ *   kind 5: kind 1 for 16 / 32 output channels on split fp16 over maps whose width is a multiple of 128 (the fusion net's
+ *           fuse_deconv1 / fuse_deconv0, flownet2.py:66-84): two row phases; each holds both column phases of its output
+ *           rows as one 2 x 3-tap convolution with 2 Cout packed rows (row b Cout + co -> pixel (2y+a, 2x+b), channel co;
+ *           tap (ty, kx3) reads input (y-1+a+ty, x-1+kx3); phase b has W[3-a-2ty][3-b-2(kx3-b)] at kx3 in {b, b+1}, zero in
+ *           its third slot); cout_pad = 2 Cout, kpad >= 6 cin_pad.  Half the passes over the input of kind 1.
  * `wgt` is the layer's weight pre-packed by fn2_pack_* layout rules (see DESIGN.md "weights"):
  *   [phase][cout_pad][kpad] elements of in.dtype, k = (tap, channel) with channels padded to a
  *   multiple of 8, kpad a multiple of the k-step; cout_pad a multiple of the block's cout tile (fn2_conv2d_plan). */
@@ -158,7 +163,7 @@ typedef struct {
   fn2_tensor out;      /* out.c = Cout; out.dtype may be FN2_F32 while in is bf16 (flow heads) */
   const void* wgt;
   const float* bias;   /* [Cout] fp32 or NULL */
-  int32_t kind;        /* 0 conv, 1 deconv 4x4 s2 crop 1, 2 stem row-run conv, 3 transpose of a stride-2 conv */
+  int32_t kind;        /* 0 conv, 1 deconv 4x4 s2 crop 1, 2 stem row-run conv, 3 transpose of a stride-2 conv, 5 = 1 with merged column phases */
   int32_t kh, kw, stride, pad;
   int32_t act;         /* fn2_act */
   int32_t cin_pad;     /* channels per tap in the packed weight (multiple of 8, >= in.c) */

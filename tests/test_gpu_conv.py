@@ -604,3 +604,43 @@ def test_flow_head5_fused(N, H, W, cin):
             if c != 4:
                 exp[:, y, xx] = lin[:, y, xx] * (1.0 + c / 10.0) + bias + c
     np.testing.assert_allclose(pf.cpu().numpy(), exp, rtol=3e-5, atol=3e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,N,H,W", [(162, 16, 2, 6, 128), (128, 32, 1, 5, 256), (96, 16, 3, 3, 128)])
+def test_deconv_merged_column_phases(cin, cout, N, H, W):
+    """fn2_conv2d kind 5: the transposed conv k4 s2 crop 1 (with bias + LeakyReLU: the fusion net's fuse_deconv0 / 1,
+    flownet2.py:66-84) with both column phases of an output row computed by one block -- against the oracle and the
+    four-phase kind 1 launch."""
+    from src import _hip, weights as Wt
+    lib = _hip.lib()
+    x = rnd((N, H, W, cin), 90)
+    w = rnd((4, 4, cout, cin), 91, (2.0 / (4 * cin)) ** 0.5)
+    b = rnd((cout,), 92, 0.5)
+    want = refnn.conv2d_transpose(x, w, activation=refnn.leaky_relu, bias=b)
+    cs = (cin + 31) // 32 * 32
+    xp = np.zeros((N, H, W, cs), np.float32)
+    xp[..., :cin] = x
+    xin = _to_dev(xp, "f16x2")
+    plan = _hip.conv_plan(3, cs, cout)
+    assert plan.layout == 1 and plan.cout_tile == 32
+    packed, cin_pad, cout_pad, kpad = Wt.pack_deconv_merged(w, plan.cout_tile, plan.kstep_elems, cs, plan.layout)
+    k2 = int(np.floor(np.log2(1024.0 / np.abs(packed).max())))
+    wdev = Wt.packed_to_device(packed * 2.0 ** k2, plan.wgt_dtype, "cuda")
+    bd = torch.from_numpy(b).cuda()
+    out = _to_dev(np.full((N, 2 * H, 2 * W, 96), 7.0, np.float32), "f16x2")
+    d = _hip.Fn2ConvDesc()
+    d.inp, d.out = _hip.view(xin, cin, 0, 3), _hip.view(out, cout, 64, 3)
+    d.wgt, d.bias = wdev.data_ptr(), bd.data_ptr()
+    d.kind, d.kh, d.kw, d.stride, d.pad, d.act = 5, 4, 4, 2, 1, 1
+    d.cin_pad, d.cout_pad, d.kpad, d.wgt_layout, d.out_scale = cin_pad, cout_pad, kpad, plan.layout, 2.0 ** -k2
+    name = C.create_string_buffer(256)
+    _hip.check(lib.fn2_conv2d_kernel_name(C.byref(d), name, 256))
+    assert name.value.decode().startswith("conv_halo_kernel"), name.value
+    _hip.check(lib.fn2_conv2d(C.byref(d), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    res = _from_dev(out, 3)
+    np.testing.assert_allclose(res[..., 64:64 + cout], want, rtol=2e-5, atol=2e-5)
+    assert np.all(res[..., :64] == 7.0) and np.all(res[..., 64 + cout:] == 7.0)
+    base = run_conv(x, w, b, "deconv", 4, 2, 1, True, "f16x2")
+    np.testing.assert_allclose(res[..., 64:64 + cout], base, rtol=1e-5, atol=1e-5)
