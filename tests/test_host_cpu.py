@@ -265,7 +265,11 @@ def test_bench_traffic_lookup_resolves_committed_profiles():
         path = os.path.join(ROOT, "profiles", "pmc_traffic_%s_b%d_f16x2.json" % (model, batch))
         if not os.path.exists(path):
             continue
-        line = json.load(open(os.path.join(ROOT, "profiles", "r01_%s_b%d_f16x2_bench.json" % (model.lower(), batch))))
+        # the newest round's committed bench line of this workload names the kernel the PMC pass was keyed on
+        import glob
+        lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*%s_b%d_f16x2_bench.json" % (model.lower(), batch))),
+                       key=os.path.basename)
+        line = json.load(open(lines[-1]))
         kern = line["roofline"]["kernel"]
         got = bench.stored_traffic(model, batch, "f16x2", kern)
         assert got is not None and got > 1e6, (model, kern)
