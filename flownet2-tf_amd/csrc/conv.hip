@@ -1382,6 +1382,21 @@ int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, 
     FN2_REQUIRE(x->c0 + a.h5_groups * 8 <= x->cs, "flow_head5: the last 8-channel group reaches past the buffer");
     total += cdiv((long)x->n * (2 * x->w + 2 * (x->h - 2)), 16);
   }
+  // Strip form (conv2.hip: head5_strip_kernel) for 96- / 192-channel runs: a block walks down a strip of 60 output
+  // columns; the row segments are cut so that the grid is one round of the chip (<= 256 blocks, 1 per CU: 112 / 136 KB
+  // of LDS).  FN2_H5_STRIP=0: the tile form (A/B).
+  {
+    const char* e = getenv("FN2_H5_STRIP");
+    if ((a.ksteps == 3 || a.ksteps == 6) && !(e && atoi(e) == 0) && !(a.dbg & 10)) {
+      const int nstrip = cdiv(x->w, 60);
+      const char* eb = getenv("FN2_H5_BLOCKS");
+      const int target = eb ? atoi(eb) : 256;
+      const int segs = std::max(1, std::min(x->h, target / std::max(1, x->n * nstrip)));
+      const int rows = cdiv(x->h, segs);
+      a.h5_tx = nstrip; a.h5_ty = cdiv(x->h, rows); a.h5_rows = rows;
+      return launch_head5_strip(a, x->n * a.h5_ty * a.h5_tx, (hipStream_t)stream);
+    }
+  }
   return launch_head5(a, (int)total, (hipStream_t)stream);
 }
 

@@ -76,47 +76,53 @@ __device__ __forceinline__ void dma16(const v4i_t rsrc, const void* lds, unsigne
 // Border ring of a composed head (fn2_flow_head_ring, conv.hip head_ring_kernel) as extra blocks of the HEAD5 launch:
 // block `rb` of the ring part takes 16 ring pixels, a wave four of them one after the other (wave per pixel: lanes stride
 // the (tap, 8-channel group) items, shuffle reduction).
-__device__ __forceinline__ void h5_ring_block(const ConvArgs& p, int rb) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void h5_ring_pixel(const ConvArgs& p, long m) {   // one wave: ring pixel m of N * ring
+  const int lane = threadIdx.x & 63;
   const int H = p.OH, W = p.OW, ring = 2 * W + 2 * (H - 2);
   const int nitems = 25 * p.h5_groups;
   const size_t case_stride = (size_t)nitems * 16;
   const x2_t* in = reinterpret_cast<const x2_t*>(p.in);
   float* pf = reinterpret_cast<float*>(p.out);
+  const int n = (int)(m / ring), r = (int)(m - (long)n * ring);
+  int y, x;
+  if (r < W) { y = 0; x = r; }
+  else if (r < 2 * W) { y = H - 1; x = r - W; }
+  else { const int q = r - 2 * W; y = 1 + (q >> 1); x = (q & 1) ? W - 1 : 0; }
+  const int cy = y == 0 ? 0 : (y == H - 1 ? 2 : 1), cx = x == 0 ? 0 : (x == W - 1 ? 2 : 1);
+  const int cs = 3 * cy + cx;
+  const float* w = p.h5_wc + (size_t)cs * case_stride;
+  float a0 = 0.f, a1 = 0.f;
+  for (int q = lane; q < nitems; q += 64) {
+    const int tap = q / p.h5_groups, gi = q - tap * p.h5_groups;
+    const int ky = tap / 5, kx = tap - ky * 5;
+    const int iy = y + ky - 2, ix = x + kx - 2;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const uint4* src = reinterpret_cast<const uint4*>(in + (((size_t)n * H + iy) * W + ix) * p.in_cs + p.in_c0 + gi * 8);
+    float xv[8];
+    join8(src[0], src[1], xv);
+    const float* u = w + (size_t)q * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 += xv[j] * u[2 * j];
+      a1 += xv[j] * u[2 * j + 1];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_xor(a0, off, 64);
+    a1 += __shfl_xor(a1, off, 64);
+  }
+  if (lane == 0)
+    *reinterpret_cast<float2*>(pf + (((size_t)n * H + y) * W + x) * 2) = make_float2(a0 + p.h5_bc[2 * cs], a1 + p.h5_bc[2 * cs + 1]);
+}
+
+__device__ __forceinline__ void h5_ring_block(const ConvArgs& p, int rb) {
+  const int wave = threadIdx.x >> 6;
+  const long total = (long)p.N * (2 * p.OW + 2 * (p.OH - 2));
   for (int k = 0; k < 4; ++k) {
     const long m = (long)rb * 16 + wave * 4 + k;
-    if (m >= (long)p.N * ring) return;
-    const int n = (int)(m / ring), r = (int)(m - (long)n * ring);
-    int y, x;
-    if (r < W) { y = 0; x = r; }
-    else if (r < 2 * W) { y = H - 1; x = r - W; }
-    else { const int q = r - 2 * W; y = 1 + (q >> 1); x = (q & 1) ? W - 1 : 0; }
-    const int cy = y == 0 ? 0 : (y == H - 1 ? 2 : 1), cx = x == 0 ? 0 : (x == W - 1 ? 2 : 1);
-    const int cs = 3 * cy + cx;
-    const float* w = p.h5_wc + (size_t)cs * case_stride;
-    float a0 = 0.f, a1 = 0.f;
-    for (int q = lane; q < nitems; q += 64) {
-      const int tap = q / p.h5_groups, gi = q - tap * p.h5_groups;
-      const int ky = tap / 5, kx = tap - ky * 5;
-      const int iy = y + ky - 2, ix = x + kx - 2;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const uint4* src = reinterpret_cast<const uint4*>(in + (((size_t)n * H + iy) * W + ix) * p.in_cs + p.in_c0 + gi * 8);
-      float xv[8];
-      join8(src[0], src[1], xv);
-      const float* u = w + (size_t)q * 16;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        a0 += xv[j] * u[2 * j];
-        a1 += xv[j] * u[2 * j + 1];
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      a0 += __shfl_xor(a0, off, 64);
-      a1 += __shfl_xor(a1, off, 64);
-    }
-    if (lane == 0)
-      *reinterpret_cast<float2*>(pf + (((size_t)n * H + y) * W + x) * 2) = make_float2(a0 + p.h5_bc[2 * cs], a1 + p.h5_bc[2 * cs + 1]);
+    if (m >= total) return;
+    h5_ring_pixel(p, m);
   }
 }
 
@@ -1199,6 +1205,149 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Composed 5x5 flow head, STRIP form (fn2_flow_head5; flownet2.py:74-77 / :90-93 fuse_interconvN + predict_flowN, the
+// two full- / half-resolution heads of the fusion net).  The tile form above (HEAD5) computes the 50 (tap, output)
+// partials on an 8 x 32 window to get 4 x 28 outputs: 2.3x the input bytes and MFMAs of the layer.  Here a block walks
+// DOWN a strip of 64 input columns (60 outputs): per input row r it forms the partial row T[50][64] (64 pixels x 64
+// packed couts x K on the matrix cores, weights resident in LDS as in conv_stem_kernel), and adds, for every tap row ky,
+// sum_kx T[(ky, kx, o)][x + kx - 2] to the accumulator of output row r + 2 - ky (a 5-row ring in LDS); output row r - 2
+// is complete when row r has been added and leaves as one 480-byte run.  Input bytes per output: 64/60 x (R + 4)/R.
+// Pixel rows come through a 3-slot LDS-DMA ring of 96-channel chunks (CPR chunks per row: 1 for the 82-channel concat0,
+// 2 for the 162-channel concat1), two chunks in flight behind the one being multiplied; counted vmcnt + raw barriers.
+// The border ring (other weights per border case, h5_ring_pixel) is shared out evenly: every block ends with its share.
+template <int CPR>
+__global__ void __launch_bounds__(256) head5_strip_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int RD = 3, CL = 3, NL = CPR * CL;
+  constexpr int TS = 68;   // floats per row of T: 64 columns + 4 (the kx shifts read columns -2 .. 65 of nothing: x is clamped to [2, 62))
+  __shared__ uint4 ldsW[NL][64 * 8];
+  __shared__ uint4 ldsX[RD][CL][64 * 8];
+  __shared__ float T[50 * TS];
+  __shared__ float accr[5 * 64 * 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 1, wp = wave & 1;
+  const int H = p.OH, W = p.OW;
+  const int nstrip = p.h5_tx, nseg = p.h5_ty, R = p.h5_rows;
+  const int b = blockIdx.x;
+  const int sx = b % nstrip, sg = (b / nstrip) % nseg, n = b / (nstrip * nseg);
+  const int x0 = sx * 60 - 2;
+  const int y0 = sg * R, y1 = min(H, y0 + R);
+  const int r0 = max(0, y0 - 2), r1 = min(H - 1, y1 + 1);
+  const int nch = (r1 - r0 + 1) * CPR;
+  const float bias_o[2] = {p.bias ? p.bias[0] : 0.f, p.bias ? p.bias[1] : 0.f};
+  const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
+  const v4i_t rsrc_w = make_rsrc(p.wgt, (int)(p.cout_pad * wrow_bytes));
+  const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
+  const int lrow = lane >> 3, lphys = lane & 7;
+  for (int i = tid; i < 5 * 64 * 2; i += 256) accr[i] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias words: no ordinary load stays pending beside the DMAs
+  // ---- weights: once
+#pragma unroll
+  for (int ln = 0; ln < NL; ++ln)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wave * 16 + j * 8 + lrow;
+      const unsigned woff = (unsigned)row * wrow_bytes + (unsigned)((lphys ^ ((row >> 1) & 7)) * 16);
+      dma16(rsrc_w, &ldsW[ln][(wave * 16 + j * 8) * 8], woff, ln * 128);
+    }
+  // chunk c = (input row r0 + c / CPR, channel lines [CL (c % CPR), +CL)); 6 DMA instructions per wave, zeros past the end
+  auto issue = [&](int c, int slot) {
+    const int rr = c / CPR, kc = c - rr * CPR;
+    const int r = r0 + rr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int px = wave * 16 + j * 8 + lrow;
+      const int x = x0 + px;
+      const bool ok = c < nch && x >= 0 && x < W;
+      const unsigned off = ok ? (unsigned)((((n * H + r) * W + x) * p.in_cs + p.in_c0) * 4 + (lphys ^ ((px >> 1) & 7)) * 16 +
+                                           kc * (CL * 128))
+                              : kOobOffset;
+#pragma unroll
+      for (int ln = 0; ln < CL; ++ln)
+        dma16(rsrc_x, &ldsX[slot][ln][(wave * 16 + j * 8) * 8], ok ? off + ln * 128 : kOobOffset, 0);
+    }
+  };
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  float* pf = reinterpret_cast<float*>(p.out);
+  f32x16 acc;
+  int slot = 0;
+  for (int c = 0; c < nch; ++c) {
+    const int rr = c / CPR, kc = c - rr * CPR;
+    const int r = r0 + rr;
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // chunks c + 1, c + 2 stay in flight (stores only make it stricter)
+    __builtin_amdgcn_s_barrier();
+    if (kc == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    }
+#pragma unroll
+    for (int ln = 0; ln < CL; ++ln) {
+      const uint4* A = &ldsW[kc * CL + ln][(wc * 32 + fr) * 8];
+      const uint4* B = &ldsX[slot][ln][(wp * 32 + fr) * 8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
+        const uint4 bh = B[chh], bl = B[chl];
+        const uint4 ah = A[chh], al = A[chl];
+        acc = mfma_32x32x16<f16_t>(al, bh, acc);
+        acc = mfma_32x32x16<f16_t>(ah, bl, acc);
+        acc = mfma_32x32x16<f16_t>(ah, bh, acc);
+      }
+    }
+    const bool last = kc == CPR - 1;
+    if (last) {   // T[(ky * 5 + kx) * 2 + o][column]: lane (column wp 32 + fr, half fh) holds packed couts [wc 32 + fh 16, +16)
+      const int cb = wc * 32 + fh * 16;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (cb + q < 50) T[(cb + q) * TS + wp * 32 + fr] = acc[q] * p.out_scale;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(c + RD, slot);     // the slot every wave has finished reading
+    slot = slot == RD - 1 ? 0 : slot + 1;
+    if (last) {
+      const int x = lane;    // column of the strip; wave g takes the (ky, o) items g, g + 4, g + 8
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int it = wave + 4 * k;
+        if (it >= 10) break;
+        const int ky = it >> 1, o = it & 1;
+        const int y = r + 2 - ky;
+        if (y < y0 || y >= y1 || x < 2 || x >= 62) continue;
+        const float* t = &T[(ky * 10 + o) * TS + x - 2];
+        float sum = t[0];
+        sum += t[2 * TS + 1];
+        sum += t[4 * TS + 2];
+        sum += t[6 * TS + 3];
+        sum += t[8 * TS + 4];
+        float* a = &accr[((y % 5) * 64 + x) * 2 + o];
+        const float v = *a + sum;
+        if (ky == 4 || r == H - 1) {   // no later input row reaches output row y
+          const int ox = x0 + x;
+          if (ox < W && !(p.h5_ring && (y == 0 || y == H - 1 || ox == 0 || ox == W - 1)))
+            pf[(((size_t)n * H + y) * W + ox) * 2 + o] = v + bias_o[o];
+          *a = 0.f;
+        } else {
+          *a = v;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.h5_wc != nullptr) {   // this block's share of the border ring, a wave per pixel
+    const long total = (long)p.N * (2 * W + 2 * (H - 2));
+    const long per = (total + gridDim.x - 1) / gridDim.x;
+    const long m1 = min(total, (long)(b + 1) * per);
+    for (long m = (long)b * per + wave; m < m1; m += 4) h5_ring_pixel(p, m);
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Row-run stems from the RAW image row (kind 2: the first layer of every network on its pre-padded few-channel input;
 // flownet_s.py:39 conv1 7x7 s2 on 12 / 6 channels, flownet_c.py:30-34 as 4x4 s1 on 2x2 super-pixels, flownet_sd.py:29
 // conv0 and flownet2.py:61 fuse_conv0 3x3 s1).  In conv_igemm2_kernel a pixel's run of KW*cs channels is fetched as
@@ -1510,6 +1659,14 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
   else FN2_LAUNCH2(cdiv(a.M, 256), a.cout_pad / 32, 256, 1, 4, 1, 2, 2, 1);
 #undef FN2_LAUNCH2
   FN2_CHECK_LAUNCH("conv_igemm2");
+  return FN2_OK;
+}
+
+int launch_head5_strip(const ConvArgs& a, int blocks, hipStream_t s) {
+  if (a.ksteps == 3) hipLaunchKernelGGL((head5_strip_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
+  else if (a.ksteps == 6) hipLaunchKernelGGL((head5_strip_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
+  else return fail(FN2_ERR_UNSUPPORTED, "flow_head5 strip form: %d channel lines (3 or 6)", a.ksteps);
+  FN2_CHECK_LAUNCH("flow_head5_strip");
   return FN2_OK;
 }
 

@@ -31,6 +31,7 @@ struct ConvArgs {
   int h5_tiles, h5_groups;    // ... blocks [h5_tiles, gridDim.x) compute the border ring from these (nullptr: no ring blocks):
   const float* h5_wc;         //     fp32 [9 cases][25 taps][8 h5_groups][2]
   const float* h5_bc;         //     fp32 [9][2]
+  int h5_rows;                // strip form (head5_strip_kernel): h5_tx = strips of 60 output columns, h5_ty = row segments, h5_rows = output rows per segment
   int wfrag;    // 1: the weight is stored in MFMA-fragment order (wgt_layout 2) and loaded straight into registers (conv2.hip, WREG)
   int accum;    // 1: out += result (fp32 outputs; gradient accumulation into shared buffers)
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
@@ -105,6 +106,7 @@ ConvNameSink& conv_name_sink();
 int launch_conv_fast(const ConvArgs& a, int in_dtype, int out_dtype, int tile, int phases, hipStream_t s);
 // conv2.hip: the composed 5x5 flow head (HEAD5 instantiation); `blocks` = n * tiles_y * tiles_x
 int launch_head5(const ConvArgs& a, int blocks, hipStream_t s);
+int launch_head5_strip(const ConvArgs& a, int blocks, hipStream_t s);
 // true when the fast kernel covers this geometry (then the packed weight must use the permuted-64 row order)
 bool conv_fast_ok(int in_dtype, int cin_pad, int cout);
 

@@ -65,7 +65,21 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class BatchTooLarge(ValueError):
+    """An activation tensor of the requested batch would reach MAX_TENSOR_BYTES: the LDS-DMA kernels address a tensor
+    through one buffer descriptor with 31-bit offsets ("limits").  `fit` = pairs per engine that keep
+    THIS tensor under the limit (a later, larger tensor may ask for fewer: callers retry -- Net.model runs the batch in
+    chunks of that many pairs)."""
+
+    def __init__(self, name, batch, nbytes, limit):
+        self.fit = max(1, int(batch * (limit - 1) // nbytes))
+        super().__init__("activation tensor %s of a batch of %d pairs is %d bytes (limit %d): at most %d pairs per engine"
+                         % (name, batch, nbytes, limit, self.fit))
+
+
 class Engine:
+    MAX_TENSOR_BYTES = 1 << 31   # fn2_conv2d refuses larger views (conv.hip: FN2_REQUIRE on in_bytes)
+
     def __init__(self, model, weights, batch, height, width, dtype="f32", device=None, heads_as_gemm=True,
                  no_deconv_biases=None, strict=True, uint8_inputs=False, plain_stems=False, fragment_weights=None):
         """uint8_inputs: the plan starts with two table look-up passes that turn uint8 image bytes (set_inputs_u8) into
@@ -176,7 +190,14 @@ class Engine:
         if dtype is None and not stem and line == 32 and 8 < c <= 32:
             cs = 32  # one line: the 16-channel interconv0 output then feeds predict_flow0 as a head GEMM
 
-        t = torch.zeros((n, h, w, cs), dtype=self.tdtype if dtype is None else dtype, device=self.device)
+        td = self.tdtype if dtype is None else dtype
+        nbytes = n * h * w * cs * torch.empty((), dtype=td).element_size()
+        if nbytes >= self.MAX_TENSOR_BYTES:
+            if self.N <= 1:
+                raise ValueError("one %d x %d pair needs a %d-byte tensor (%s): above the %d-byte limit of the kernels"
+                                 % (self.H, self.W, nbytes, name, self.MAX_TENSOR_BYTES))
+            raise BatchTooLarge(name, self.N, nbytes, self.MAX_TENSOR_BYTES)
+        t = torch.zeros((n, h, w, cs), dtype=td, device=self.device)
         assert name not in self.bufs, name
         self.bufs[name] = t
         self.code_of[t.data_ptr()] = self.act_code if dtype is None else _hip.FN2_F32
@@ -477,9 +498,11 @@ class Engine:
             b5 = W.to_device(bias5[4].astype(np.float32), torch.float32, self.device)
             vx = self._v(sbuf, sc, sc0)
             self.keep += [wdev, b5, vx]
+            strip = cin_pad in (96, 192) and int(os.environ.get("FN2_H5_STRIP", "1"))   # conv.hip: fn2_flow_head5
             self._op(f"{scope}/{ic_name}+{pf_name}", self.lib.fn2_flow_head5, C.byref(vx), _hip.ptr(wdev), cin_pad, kpad,
                      C.c_float(out_scale), _hip.ptr(b5), _hip.ptr(pf), 1, _hip.ptr(wcd), _hip.ptr(bcd),
-                     kernel="conv_igemm2_kernel<fn2::x2_t, float, 1, 4, 2, 2, 2, 1, false, false, false, true>")
+                     kernel=("head5_strip_kernel<%d>" % (cin_pad // 96)) if strip else
+                     "conv_igemm2_kernel<fn2::x2_t, float, 1, 4, 2, 2, 2, 1, false, false, false, true>")
             self.layer_flops.append((f"{scope}/{ic_name}+{pf_name}", 2.0 * n * h * wd * 9 * (sc * cm + cm * 2)))
             self.layer_io_bytes.append((f"{scope}/{ic_name}+{pf_name}", float(n * h * wd * (sc * 4 + 2 * 4) + 9 * (sc * cm + 2 * cm) * 4)))
             return 1

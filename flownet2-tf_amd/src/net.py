@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import weights as W
-from .engine import Engine
+from .engine import BatchTooLarge, Engine
 from .flowlib import compute_all_metrics, flow_to_image, get_metrics, read_flow, write_flow
 from .training_schedules import LONG_SCHEDULE
 
@@ -46,6 +46,7 @@ class Net(object):
         self.dtype = dtype
         self.weights = None
         self._engines = {}
+        self._chunk_of = {}   # (height, width, dtype) -> pairs per engine when the whole batch does not fit (model())
 
     # ---- weights -----------------------------------------------------------------------------
     def load_weights(self, checkpoint=None, seed=1234):
@@ -85,17 +86,34 @@ class Net(object):
         fp32 ROCm tensors."""
         a, b = inputs['input_a'], inputs['input_b']
         n, h, w, _ = a.shape
-        if _is_u8(a) and _is_u8(b):
-            # un-normalised uint8 frames (adapt_x_u8): the bytes go to the device as they are and the `/ 255.0` of
-            # adapt_x (net.py:338-345) runs there -- byte-identical, a quarter of the host-link traffic
-            eng = self.engine(int(n), int(h), int(w), uint8_inputs=True)
-            eng.set_inputs_u8(a, b, scale=inputs.get('scale', (int(a.max()) > 1, int(b.max()) > 1)))
-            eng.launch()
-            out = eng.outputs
-        else:
-            eng = self.engine(int(n), int(h), int(w))
-            out = eng(a, b)
-        return {k: v.clone() for k, v in out.items()}
+        u8 = _is_u8(a) and _is_u8(b)
+        scale = inputs.get('scale', (int(a.max()) > 1, int(b.max()) > 1)) if u8 else None
+        # a batch whose activation tensors would pass the kernels' 2 GiB addressing limit runs as chunks of the
+        # largest batch that fits (the convolutions are per-pair: chunking changes no value); the chunk size found
+        # for a shape is remembered
+        chunk = self._chunk_of.get((int(h), int(w), self.dtype), int(n))
+        outs, i = [], 0
+        while i < n:
+            m = min(chunk, int(n) - i)
+            try:
+                eng = self.engine(m, int(h), int(w), uint8_inputs=u8)
+            except BatchTooLarge as e:
+                chunk = min(e.fit, m - 1)
+                self._chunk_of[(int(h), int(w), self.dtype)] = chunk
+                continue
+            if u8:
+                # un-normalised uint8 frames (adapt_x_u8): the bytes go to the device as they are and the `/ 255.0` of
+                # adapt_x (net.py:338-345) runs there -- byte-identical, a quarter of the host-link traffic
+                eng.set_inputs_u8(a[i:i + m], b[i:i + m], scale=scale)
+                eng.launch()
+                out = eng.outputs
+            else:
+                out = eng(a[i:i + m], b[i:i + m])
+            outs.append({k: v.clone() for k, v in out.items()})
+            i += m
+        if len(outs) == 1:
+            return outs[0]
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
     # ---- test-time input adaptation ---------------------------------------------------------------
     def get_padded_image_size(self, og_height, og_width, divisor=64):

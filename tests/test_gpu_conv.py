@@ -547,12 +547,18 @@ def test_conv_fragment_order_weights(kind, k, s, p, cin, cout, N, H, W, out_f32)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,H,W,cin", [(2, 37, 61, 82), (1, 8, 56, 162), (3, 5, 9, 32)])
-def test_flow_head5_fused(N, H, W, cin):
+@pytest.mark.parametrize("N,H,W,cin,blocks", [(2, 37, 61, 82, None), (1, 8, 56, 162, None), (3, 5, 9, 32, None),
+                                               (1, 70, 130, 82, None), (1, 70, 130, 82, 8), (2, 33, 64, 162, 6),
+                                               (1, 3, 3, 82, None)])
+def test_flow_head5_fused(N, H, W, cin, blocks, monkeypatch):
     """fn2_flow_head5: a 5x5 two-output convolution (the composed interconvN + predict_flowN head) with the 50 partials
     of a position formed on the matrix cores and summed from LDS -- against the oracle's conv2d with zero padding 2
-    (ring = 0), and with ring = 1 the outermost pixel ring left exactly as pf held it."""
+    (ring = 0), and with ring = 1 the outermost pixel ring left exactly as pf held it.  96- / 192-channel runs take the
+    strip form (a block walks down 60 output columns; `blocks` = FN2_H5_BLOCKS, the grid the row segments are cut for:
+    one-row segments, several strips, many rows per block), 32 channels the tile form."""
     from src import _hip, weights as Wt
+    if blocks is not None:
+        monkeypatch.setenv("FN2_H5_BLOCKS", str(blocks))
     lib = _hip.lib()
     x = rnd((N, H, W, cin), 80)
     w5 = rnd((5, 5, cin, 2), 81, (1.0 / (25 * cin)) ** 0.5)

@@ -429,3 +429,40 @@ def test_uint8_input_path_is_byte_identical_to_the_fp32_path():
     assert np.array_equal(dst.cpu().numpy(), (src.cpu().numpy() / 255.0).astype(np.float32))
     with pytest.raises(ValueError):
         Engine("FlowNetC", wts, 1, 64, 64, "f32").set_inputs_u8(u1, u2)
+
+
+@pytest.mark.gpu
+def test_model_runs_a_batch_above_the_tensor_limit_in_chunks(monkeypatch):
+    """The LDS-DMA kernels address one tensor through 31-bit offsets, so a batch whose largest activation tensor would
+    reach 2 GiB cannot be one engine (limits).  Net.model then runs the batch as chunks of the largest
+    batch that fits: same predictions, in the caller's order.  Here the limit is lowered so that 5 pairs of 128 x 192 do
+    not fit (conv1: 5 x 64 x 96 x 64 channels x 4 bytes = 7.9 MB against a limit of 4 MiB -> 2 pairs per engine)."""
+    from src.engine import BatchTooLarge, Engine
+    from src.flownet_s.flownet_s import FlowNetS
+    from src.net import Mode
+    rng = np.random.default_rng(8)
+    a = rng.random((5, 128, 192, 3), dtype=np.float32)
+    b = np.roll(a, (1, -2), (1, 2))
+    net = FlowNetS(mode=Mode.TEST, dtype="f16x2")
+    net.load_weights(None, seed=3)
+    whole = net.model({"input_a": a, "input_b": b})
+    monkeypatch.setattr(Engine, "MAX_TENSOR_BYTES", 4 << 20)
+    with pytest.raises(BatchTooLarge) as e:
+        Engine("FlowNetS", net.weights, 5, 128, 192, "f16x2")
+    assert 1 <= e.value.fit < 5
+    net2 = FlowNetS(mode=Mode.TEST, dtype="f16x2")
+    net2.load_weights(None, seed=3)
+    parts = net2.model({"input_a": a, "input_b": b})
+    chunk = net2._chunk_of[(128, 192, "f16x2")]
+    assert 1 <= chunk < 5 and all(k[0] <= chunk for k in net2._engines)
+    assert set(parts) == set(whole)
+    for k in whole:
+        assert parts[k].shape == whole[k].shape
+        # another batch size may pick another tile / split for a layer: equal to rounding, not bit for bit
+        assert float((parts[k] - whole[k]).abs().max()) <= 2e-5 * max(1.0, float(whole[k].abs().max())), k
+    # one pair that does not fit by itself is an error, not an endless retry
+    monkeypatch.setattr(Engine, "MAX_TENSOR_BYTES", 1 << 20)
+    net3 = FlowNetS(mode=Mode.TEST, dtype="f16x2")
+    net3.load_weights(None, seed=3)
+    with pytest.raises(ValueError):
+        net3.model({"input_a": a[:2], "input_b": b[:2]})
