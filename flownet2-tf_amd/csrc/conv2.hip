@@ -92,19 +92,39 @@ __device__ __forceinline__ void h5_ring_pixel(const ConvArgs& p, long m) {   // 
   const int cs = 3 * cy + cx;
   const float* w = p.h5_wc + (size_t)cs * case_stride;
   float a0 = 0.f, a1 = 0.f;
-  for (int q = lane; q < nitems; q += 64) {
-    const int tap = q / p.h5_groups, gi = q - tap * p.h5_groups;
-    const int ky = tap / 5, kx = tap - ky * 5;
-    const int iy = y + ky - 2, ix = x + kx - 2;
-    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    const uint4* src = reinterpret_cast<const uint4*>(in + (((size_t)n * H + iy) * W + ix) * p.in_cs + p.in_c0 + gi * 8);
-    float xv[8];
-    join8(src[0], src[1], xv);
-    const float* u = w + (size_t)q * 16;
+  constexpr int U = 5;   // items per lane whose loads are in flight together (a pixel is 5 / 9 of them on 82 / 162 channels)
+  for (int q0 = lane; q0 < nitems; q0 += 64 * U) {
+    uint4 xs[U][2];
+    float4 ws[U][4];
+    bool ok[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      a0 += xv[j] * u[2 * j];
-      a1 += xv[j] * u[2 * j + 1];
+    for (int k = 0; k < U; ++k) {
+      const int q = min(q0 + 64 * k, nitems - 1);
+      const int tap = q / p.h5_groups, gi = q - tap * p.h5_groups;
+      const int ky = tap / 5, kx = tap - ky * 5;
+      const int iy = y + ky - 2, ix = x + kx - 2;
+      ok[k] = q0 + 64 * k < nitems && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int cy2 = min(max(iy, 0), H - 1), cx2 = min(max(ix, 0), W - 1);
+      const uint4* src = reinterpret_cast<const uint4*>(in + (((size_t)n * H + cy2) * W + cx2) * p.in_cs + p.in_c0 + gi * 8);
+      xs[k][0] = src[0];
+      xs[k][1] = src[1];
+      const float4* u = reinterpret_cast<const float4*>(w + (size_t)q * 16);   // [ci 0..7][o 0..1]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ws[k][j] = u[j];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      float xv[8];
+      join8(xs[k][0], xs[k][1], xv);
+      if (ok[k]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a0 += xv[2 * j] * ws[k][j].x;
+          a1 += xv[2 * j] * ws[k][j].y;
+          a0 += xv[2 * j + 1] * ws[k][j].z;
+          a1 += xv[2 * j + 1] * ws[k][j].w;
+        }
+      }
     }
   }
 #pragma unroll
@@ -1212,21 +1232,27 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p, const 
 // packed couts x K on the matrix cores, weights resident in LDS as in conv_stem_kernel), and adds, for every tap row ky,
 // sum_kx T[(ky, kx, o)][x + kx - 2] to the accumulator of output row r + 2 - ky (a 5-row ring in LDS); output row r - 2
 // is complete when row r has been added and leaves as one 480-byte run.  Input bytes per output: 64/60 x (R + 4)/R.
-// Pixel rows come through a 3-slot LDS-DMA ring of 96-channel chunks (CPR chunks per row: 1 for the 82-channel concat0,
-// 2 for the 162-channel concat1), two chunks in flight behind the one being multiplied; counted vmcnt + raw barriers.
+// Eight waves: 0-3 multiply (wave = 32 couts x 32 pixels) and write T; 4-7 only feed the 4-slot LDS-DMA ring of
+// 96-channel chunks (CPR chunks per row: 1 for the 82-channel concat0, 2 for the 162-channel concat1) -- the ~150
+// cycles each DMA piece costs its wave to issue (24 pieces per chunk) run beside the MFMAs on the SIMD's other wave
+// slot instead of in front of them; counted vmcnt + raw barriers.  All eight gather.  Measured on the first form (four
+// waves doing everything, 3 slots; tools/diag/h5_ablate.py, 4x384x512x82): DMA + barriers 51 us, + MFMA 67, + gather 99
+// (three dependent LDS round trips per item behind branches: batched here), + ring share 126.
 // The border ring (other weights per border case, h5_ring_pixel) is shared out evenly: every block ends with its share.
 template <int CPR>
-__global__ void __launch_bounds__(256) head5_strip_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(512) head5_strip_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int RD = 3, CL = 3, NL = CPR * CL;
-  constexpr int TS = 68;   // floats per row of T: 64 columns + 4 (the kx shifts read columns -2 .. 65 of nothing: x is clamped to [2, 62))
+  constexpr int RD = 4, CL = 3, NL = CPR * CL;   // ring slots (five for the 96-channel form measured the same)
+  constexpr int TS = 68;   // floats per row of T (64 columns; + 4 moves consecutive rows onto other banks)
   __shared__ uint4 ldsW[NL][64 * 8];
   __shared__ uint4 ldsX[RD][CL][64 * 8];
   __shared__ float T[50 * TS];
   __shared__ float accr[5 * 64 * 2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave >> 1, wp = wave & 1;
+  const bool feeder = wave >= 4;
+  const int w4 = wave & 3;
+  const int wc = w4 >> 1, wp = w4 & 1;
   const int H = p.OH, W = p.OW;
   const int nstrip = p.h5_tx, nseg = p.h5_ty, R = p.h5_rows;
   const int b = blockIdx.x;
@@ -1240,24 +1266,14 @@ __global__ void __launch_bounds__(256) head5_strip_kernel(const ConvArgs p) {
   const v4i_t rsrc_w = make_rsrc(p.wgt, (int)(p.cout_pad * wrow_bytes));
   const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
   const int lrow = lane >> 3, lphys = lane & 7;
-  for (int i = tid; i < 5 * 64 * 2; i += 256) accr[i] = 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias words: no ordinary load stays pending beside the DMAs
-  // ---- weights: once
-#pragma unroll
-  for (int ln = 0; ln < NL; ++ln)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wave * 16 + j * 8 + lrow;
-      const unsigned woff = (unsigned)row * wrow_bytes + (unsigned)((lphys ^ ((row >> 1) & 7)) * 16);
-      dma16(rsrc_w, &ldsW[ln][(wave * 16 + j * 8) * 8], woff, ln * 128);
-    }
-  // chunk c = (input row r0 + c / CPR, channel lines [CL (c % CPR), +CL)); 6 DMA instructions per wave, zeros past the end
+  for (int i = tid; i < 5 * 64 * 2; i += 512) accr[i] = 0.f;
+  // chunk c = (input row r0 + c / CPR, channel lines [CL (c % CPR), +CL)); 6 DMA pieces per feeder wave, zeros past the end
   auto issue = [&](int c, int slot) {
     const int rr = c / CPR, kc = c - rr * CPR;
     const int r = r0 + rr;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int px = wave * 16 + j * 8 + lrow;
+      const int px = w4 * 16 + j * 8 + lrow;
       const int x = x0 + px;
       const bool ok = c < nch && x >= 0 && x < W;
       const unsigned off = ok ? (unsigned)((((n * H + r) * W + x) * p.in_cs + p.in_c0) * 4 + (lphys ^ ((px >> 1) & 7)) * 16 +
@@ -1265,12 +1281,22 @@ __global__ void __launch_bounds__(256) head5_strip_kernel(const ConvArgs p) {
                               : kOobOffset;
 #pragma unroll
       for (int ln = 0; ln < CL; ++ln)
-        dma16(rsrc_x, &ldsX[slot][ln][(wave * 16 + j * 8) * 8], ok ? off + ln * 128 : kOobOffset, 0);
+        dma16(rsrc_x, &ldsX[slot][ln][(w4 * 16 + j * 8) * 8], ok ? off + ln * 128 : kOobOffset, 0);
     }
   };
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
+  if (feeder) {
+    // ---- weights: once
+#pragma unroll
+    for (int ln = 0; ln < NL; ++ln)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = w4 * 16 + j * 8 + lrow;
+        const unsigned woff = (unsigned)row * wrow_bytes + (unsigned)((lphys ^ ((row >> 1) & 7)) * 16);
+        dma16(rsrc_w, &ldsW[ln][(w4 * 16 + j * 8) * 8], woff, ln * 128);
+      }
+#pragma unroll
+    for (int c = 0; c < RD - 1; ++c) issue(c, c);
+  }
   const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
   float* pf = reinterpret_cast<float*>(p.out);
   f32x16 acc;
@@ -1278,74 +1304,98 @@ __global__ void __launch_bounds__(256) head5_strip_kernel(const ConvArgs p) {
   for (int c = 0; c < nch; ++c) {
     const int rr = c / CPR, kc = c - rr * CPR;
     const int r = r0 + rr;
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // chunks c + 1, c + 2 stay in flight (stores only make it stricter)
+    if (feeder) {   // chunks c + 1 .. c + RD - 2 stay in flight (6 pieces each)
+      if constexpr (RD == 5) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (the gather's accumulator writes)
     __builtin_amdgcn_s_barrier();
-    if (kc == 0) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    }
-#pragma unroll
-    for (int ln = 0; ln < CL; ++ln) {
-      const uint4* A = &ldsW[kc * CL + ln][(wc * 32 + fr) * 8];
-      const uint4* B = &ldsX[slot][ln][(wp * 32 + fr) * 8];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
-        const uint4 bh = B[chh], bl = B[chl];
-        const uint4 ah = A[chh], al = A[chl];
-        acc = mfma_32x32x16<f16_t>(al, bh, acc);
-        acc = mfma_32x32x16<f16_t>(ah, bl, acc);
-        acc = mfma_32x32x16<f16_t>(ah, bh, acc);
-      }
-    }
     const bool last = kc == CPR - 1;
-    if (last) {   // T[(ky * 5 + kx) * 2 + o][column]: lane (column wp 32 + fr, half fh) holds packed couts [wc 32 + fh 16, +16)
-      const int cb = wc * 32 + fh * 16;
+    if (feeder) {
+      issue(c + RD - 1, slot == 0 ? RD - 1 : slot - 1);   // the slot of chunk c - 1: every wave passed its MFMAs a barrier ago
+    } else {
+      if (kc == 0) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        if (cb + q < 50) T[(cb + q) * TS + wp * 32 + fr] = acc[q] * p.out_scale;
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      }
+      if (!(p.dbg & 64))   // (ablation bits 64 / 32 / 16: no MFMA / no gather / no ring share; timing only)
+#pragma unroll
+      for (int ln = 0; ln < CL; ++ln) {
+        const uint4* A = &ldsW[kc * CL + ln][(wc * 32 + fr) * 8];
+        const uint4* B = &ldsX[slot][ln][(wp * 32 + fr) * 8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int chh = (4 * q + 2 * fh) ^ fsw, chl = (4 * q + 2 * fh + 1) ^ fsw;
+          const uint4 bh = B[chh], bl = B[chl];
+          const uint4 ah = A[chh], al = A[chl];
+          acc = mfma_32x32x16<f16_t>(al, bh, acc);
+          acc = mfma_32x32x16<f16_t>(ah, bl, acc);
+          acc = mfma_32x32x16<f16_t>(ah, bh, acc);
+        }
+      }
+      if (last) {   // T[(ky * 5 + kx) * 2 + o][column]: lane (column wp 32 + fr, half fh) holds packed couts [wc 32 + fh 16, +16)
+        const int cb = wc * 32 + fh * 16;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (cb + q < 50) T[(cb + q) * TS + wp * 32 + fr] = acc[q] * p.out_scale;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(c + RD, slot);     // the slot every wave has finished reading
     slot = slot == RD - 1 ? 0 : slot + 1;
-    if (last) {
-      const int x = lane;    // column of the strip; wave g takes the (ky, o) items g, g + 4, g + 8
+    if (last && !(p.dbg & 32)) {
+      // all eight waves add: wave g the (ky, o) items g and g + 8 (waves 0, 1) for column x = lane (measured: the four
+      // multiplying waves alone, three items each, 89 against 81 us).  Every LDS word is fetched before the first use, no
+      // branch in front of the loads (clamped addresses, results selected)
+      const int x = lane;
+      const int xc = min(max(x, 2), 61);
+      float tv[2][5], av[2];
+      int ai[2];
+      bool ok[2], fin[2];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int it = wave + 4 * k;
-        if (it >= 10) break;
+      for (int k = 0; k < 2; ++k) {
+        const int it = min(wave + 8 * k, 9);
         const int ky = it >> 1, o = it & 1;
         const int y = r + 2 - ky;
-        if (y < y0 || y >= y1 || x < 2 || x >= 62) continue;
-        const float* t = &T[(ky * 10 + o) * TS + x - 2];
-        float sum = t[0];
-        sum += t[2 * TS + 1];
-        sum += t[4 * TS + 2];
-        sum += t[6 * TS + 3];
-        sum += t[8 * TS + 4];
-        float* a = &accr[((y % 5) * 64 + x) * 2 + o];
-        const float v = *a + sum;
-        if (ky == 4 || r == H - 1) {   // no later input row reaches output row y
+        ok[k] = wave + 8 * k < 10 && y >= y0 && y < y1 && x >= 2 && x < 62;
+        fin[k] = ky == 4 || r == H - 1;   // no later input row reaches output row y
+        const int ys = ((y % 5) + 5) % 5;
+        ai[k] = (ys * 64 + xc) * 2 + o;
+        const float* t = &T[(ky * 10 + o) * TS + xc - 2];
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) tv[k][kx] = t[2 * kx * TS + kx];
+        av[k] = accr[ai[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int it = min(wave + 8 * k, 9);
+        const int ky = it >> 1, o = it & 1;
+        const int y = r + 2 - ky;
+        float sum = tv[k][0];
+        sum += tv[k][1];
+        sum += tv[k][2];
+        sum += tv[k][3];
+        sum += tv[k][4];
+        const float v = av[k] + sum;
+        if (ok[k]) {
+          accr[ai[k]] = fin[k] ? 0.f : v;
           const int ox = x0 + x;
-          if (ox < W && !(p.h5_ring && (y == 0 || y == H - 1 || ox == 0 || ox == W - 1)))
+          if (fin[k] && ox < W && !(p.h5_ring && (y == 0 || y == H - 1 || ox == 0 || ox == W - 1)))
             pf[(((size_t)n * H + y) * W + ox) * 2 + o] = v + bias_o[o];
-          *a = 0.f;
-        } else {
-          *a = v;
         }
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (p.h5_wc != nullptr) {   // this block's share of the border ring, a wave per pixel
+  if (p.h5_wc != nullptr && !(p.dbg & 16)) {   // this block's share of the border ring, a wave per pixel
     const long total = (long)p.N * (2 * W + 2 * (H - 2));
     const long per = (total + gridDim.x - 1) / gridDim.x;
     const long m1 = min(total, (long)(b + 1) * per);
-    for (long m = (long)b * per + wave; m < m1; m += 4) h5_ring_pixel(p, m);
+    for (long m = (long)b * per + wave; m < m1; m += 8) h5_ring_pixel(p, m);
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Row-run stems from the RAW image row (kind 2: the first layer of every network on its pre-padded few-channel input;
@@ -1663,8 +1713,8 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
 }
 
 int launch_head5_strip(const ConvArgs& a, int blocks, hipStream_t s) {
-  if (a.ksteps == 3) hipLaunchKernelGGL((head5_strip_kernel<1>), dim3(blocks), dim3(256), 0, s, a);
-  else if (a.ksteps == 6) hipLaunchKernelGGL((head5_strip_kernel<2>), dim3(blocks), dim3(256), 0, s, a);
+  if (a.ksteps == 3) hipLaunchKernelGGL((head5_strip_kernel<1>), dim3(blocks), dim3(512), 0, s, a);
+  else if (a.ksteps == 6) hipLaunchKernelGGL((head5_strip_kernel<2>), dim3(blocks), dim3(512), 0, s, a);
   else return fail(FN2_ERR_UNSUPPORTED, "flow_head5 strip form: %d channel lines (3 or 6)", a.ksteps);
   FN2_CHECK_LAUNCH("flow_head5_strip");
   return FN2_OK;
