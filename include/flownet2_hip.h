@@ -234,9 +234,13 @@ int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, fl
  *   pf[n,y,x,o] = bias[o] + sum_{u in 5x5} sum_ci w5[u][ci][o] x[n, y+uy-2, x+ux-2, ci]            (x zero outside the image)
  * x: split-fp16 view whose channel run is whole 128-byte lines (cin_pad % 32 == 0, c0 + cin_pad <= cs); wgt: the 1x1
  * matrix [64 rows (50 used: (uy*5+ux)*2+o)][cin_pad] in fn2_conv2d's wgt_layout 1 for a 64-row tile, split fp16, scaled by
- * 1 / out_scale; pf dense fp32 [n,h,w,2].  A block forms the 50 partials of the 8 x 32 positions around a 4 x 28 output
- * tile on the matrix cores, keeps them in LDS and sums the 25 shifted ones per output.
- * ring != 0 with ring_w / ring_b (fn2_flow_head_ring's wc / bc): extra blocks of the same launch compute the ring pixels;
+ * 1 / out_scale; pf dense fp32 [n,h,w,2].  Two forms, chosen by the library: cin_pad = 96 or 192 -> a block walks down a
+ * strip of 60 output columns, forms the 50 partials of one input row at a time on the matrix cores and adds them, per tap
+ * row, into a five-row accumulator ring in LDS (input read ~1.15 times); else a block forms the partials of the 8 x 32
+ * positions around a 4 x 28 output tile, keeps them in LDS and sums the 25 shifted ones per output.  The order of the 25
+ * additions differs between the two forms (strip: kx inside ky, bias last), so they agree to fp32 rounding, not bit for bit.
+ * ring != 0 with ring_w / ring_b (fn2_flow_head_ring's wc / bc): the same launch computes the ring pixels (extra blocks
+ * of the tile form; an even share at the end of every block of the strip form);
  * with ring_w == NULL they are left as they are (written by fn2_flow_head_ring, or not needed). */
 int fn2_flow_head5(const fn2_tensor* x, const void* wgt, int cin_pad, int kpad, float out_scale, const float* bias, float* pf,
                    int ring, const float* ring_w, const float* ring_b, void* stream);
