@@ -248,13 +248,41 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
                                                               OutT* __restrict__ out, long npix, int ws_cs, int splitk,
                                                               int Cout, int out_cs, int out_c0, int act, int vec_ok,
                                                               float out_scale, int accum, const OutT* __restrict__ mask_y,
-                                                              int mask_c0, int mask_c1) {
+                                                              int mask_c0, int mask_c1, const float* __restrict__ up_src,
+                                                              const float* __restrict__ up_w, const float* __restrict__ up_bias,
+                                                              int up_c0, int out_H, int out_W) {
   const int groups = ws_cs / 4;
-  const long total = npix * groups;
+  const int groups_all = groups + (up_src != nullptr ? 1 : 0);
+  const long total = npix * groups_all;
   const size_t slab = (size_t)npix * ws_cs;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long pix = i / groups;
-    const int co = (int)(i - pix * groups) * 4;
+    const long pix = i / groups_all;
+    const int co = (int)(i - pix * groups_all) * 4;
+    if (co == groups * 4) {
+      // fn2_conv_desc.up_src: upsample_flowXtoY for this output pixel (upsample_flow_kernel's arithmetic, tap for tap)
+      const int ox = (int)(pix % out_W), oy = (int)((pix / out_W) % out_H), n = (int)(pix / out_W / out_H);
+      const int H = out_H >> 1, W = out_W >> 1;
+      const int a = oy & 1, b = ox & 1, y = oy >> 1, x = ox >> 1;
+      float r0 = up_bias ? up_bias[0] : 0.f, r1 = up_bias ? up_bias[1] : 0.f;
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        const int iy = y - 1 + a + ty, ky = 3 - a - 2 * ty;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int tx = 0; tx < 2; ++tx) {
+          const int ix = x - 1 + b + tx, kx = 3 - b - 2 * tx;
+          if (ix < 0 || ix >= W) continue;
+          const float2 v = *reinterpret_cast<const float2*>(up_src + (((long)n * H + iy) * W + ix) * 2);
+          const float* ww = up_w + (ky * 4 + kx) * 4;
+          r0 += v.x * ww[0] + v.y * ww[1];
+          r1 += v.x * ww[2] + v.y * ww[3];
+        }
+      }
+      OutT* pu = out + (size_t)pix * out_cs + up_c0;
+      store_elem<OutT>(pu, r0);
+      store_elem<OutT>(pu + 1, r1);
+      continue;
+    }
     float4 v = *reinterpret_cast<const float4*>(ws + pix * ws_cs + co);
     int s = 1;
     for (; s + 3 < splitk; s += 4) {  // four slabs in flight; added in split order
@@ -950,6 +978,9 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
               "conv2d: kind must be 0 (conv), 1 (deconv k4 s2 crop 1), 2 (stem row-run conv), 3 (transpose of a stride-2 conv) "
               "or 5 (deconv k4 s2 crop 1, column phases merged)");
   FN2_REQUIRE(d->in.n == d->out.n, "conv2d: batch mismatch");
+  FN2_REQUIRE(d->up_src == nullptr || (d->kind == 1 && d->up_w != nullptr && d->up_c0 >= 0 && d->up_c0 + 2 <= d->out.cs &&
+                                       !d->accumulate),
+              "conv2d: up_src rides on a kind-1 transposed conv (up_w set, [up_c0, up_c0 + 2) inside the out buffer)");
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cin_pad >= d->in.c, "conv2d: cin_pad must be a multiple of 8 >= Cin");
   FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: input channel stride/offset must be multiples of 8");
   if (d->kind != 2)
@@ -1284,21 +1315,29 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   else if (d->in.dtype == FN2_BF16) rc = launch_conv<bf16_t, float>(a, tile, phases, s);
   else if (d->out.dtype == FN2_F16) rc = launch_conv<f16_t, f16_t>(a, tile, phases, s);
   else rc = launch_conv<f16_t, float>(a, tile, phases, s);
-  if (rc || a.splitk == 1 || conv_name_sink().buf || (a.dbg & 524288)) return rc;  // (524288: ablation, no finalize pass)
+  if (rc || conv_name_sink().buf) return rc;
+  if (a.splitk == 1) {
+    if (d->up_src == nullptr) return rc;
+    // no finalize pass to ride on: the stand-alone upsample_flow kernel behind the convolution
+    fn2_tensor uv = d->out;
+    uv.c = 2; uv.c0 = d->up_c0;
+    return fn2_upsample_flow(d->up_src, d->up_w, d->up_bias, &uv, d->out.n, d->out.h / 2, d->out.w / 2, stream);
+  }
+  if (a.dbg & 524288) return rc;  // (524288: ablation, no finalize pass)
   const long npix = (long)a.N * a.out_H * a.out_W;
-  const int fgrid = grid_for(npix * (a.ws_cs / 4), 256);
+  const int fgrid = grid_for(npix * (a.ws_cs / 4 + (d->up_src != nullptr ? 1 : 0)), 256);
   if (d->out.dtype == FN2_F32)
     hipLaunchKernelGGL(splitk_finalize_kernel<float>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (float*)a.out, npix,
-                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const float*)a.mask_y, a.mask_c0, a.mask_c1);
+                       a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const float*)a.mask_y, a.mask_c0, a.mask_c1, d->up_src, d->up_w, d->up_bias, d->up_c0, a.out_H, a.out_W);
   else if (d->out.dtype == FN2_F16X2)
     hipLaunchKernelGGL(splitk_finalize_kernel<x2_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (x2_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const x2_t*)a.mask_y, a.mask_c0, a.mask_c1);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const x2_t*)a.mask_y, a.mask_c0, a.mask_c1, d->up_src, d->up_w, d->up_bias, d->up_c0, a.out_H, a.out_W);
   else if (d->out.dtype == FN2_BF16)
     hipLaunchKernelGGL(splitk_finalize_kernel<bf16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (bf16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const bf16_t*)a.mask_y, a.mask_c0, a.mask_c1);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const bf16_t*)a.mask_y, a.mask_c0, a.mask_c1, d->up_src, d->up_w, d->up_bias, d->up_c0, a.out_H, a.out_W);
   else
     hipLaunchKernelGGL(splitk_finalize_kernel<f16_t>, dim3(fgrid), dim3(256), 0, s, a.ws, a.bias, (f16_t*)a.out,
-                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const f16_t*)a.mask_y, a.mask_c0, a.mask_c1);
+                       npix, a.ws_cs, a.splitk, a.Cout, a.out_cs, a.out_c0, a.act, a.vec_ok, a.out_scale, a.accum, (const f16_t*)a.mask_y, a.mask_c0, a.mask_c1, d->up_src, d->up_w, d->up_bias, d->up_c0, a.out_H, a.out_W);
   FN2_CHECK_LAUNCH("splitk_finalize");
   return FN2_OK;
 }

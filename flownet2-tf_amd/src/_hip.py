@@ -33,7 +33,8 @@ class Fn2ConvDesc(C.Structure):
                 ("kind", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("pad", C.c_int32), ("act", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
                 ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("act_grad_y", C.c_void_p), ("act_grad_c0", C.c_int32), ("act_grad_c1", C.c_int32)]
+                ("act_grad_y", C.c_void_p), ("act_grad_c0", C.c_int32), ("act_grad_c1", C.c_int32),
+                ("up_src", C.c_void_p), ("up_w", C.c_void_p), ("up_bias", C.c_void_p), ("up_c0", C.c_int32)]
 
 
 class Fn2BwdwDesc(C.Structure):

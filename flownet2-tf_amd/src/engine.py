@@ -280,10 +280,12 @@ class Engine:
         self.branch_of.append(self._branch)
 
     # ------------------------------------------------------------------ layers
-    def _conv(self, scope, spec, src, dst, up=None):
+    def _conv(self, scope, spec, src, dst, up=None, up_after=None):
         """src/dst: (buffer, c0, c).  One fn2_conv2d launch.  up (flow heads only): (name of the upsample_flowXtoY layer
         that follows the head, its destination slice) -- returns True when that upsample was fused into the head's tail
-        launch (the caller then emits no fn2_upsample_flow for it)."""
+        launch (the caller then emits no fn2_upsample_flow for it).  up_after (transposed convs only): (layer name,
+        predict_flow(N+1) buffer, destination slice) of the upsample_flow(N+1)toN that writes the neighbouring slice of
+        the same concat buffer: it rides on this launch (fn2_conv_desc.up_src: the split-K finalize pass does it)."""
         name, kind, k, stride, pad, cin, cout, act = spec
         sbuf, sc0, sc = src
         dbuf, dc0, dc = dst
@@ -348,11 +350,24 @@ class Engine:
         self.keep += [d, wdev, bias]
         self.conv_descs.append(d)
         self.desc_branch.append(self._branch)
+        up_rec = None
+        if up_after is not None:
+            assert kind != "conv" and not merged
+            up_name, up_src, (ubuf, uc0, uc) = up_after
+            assert ubuf is dbuf and uc == 2
+            uw = W.to_device(self._w(f"{scope}/{up_name}/weights"), torch.float32, self.device)
+            ub = self._bias(scope, up_name, "deconv", 2)
+            d.up_src, d.up_w, d.up_bias, d.up_c0 = up_src.data_ptr(), uw.data_ptr(), (ub.data_ptr() if ub is not None else None), uc0
+            uv = self._v(ubuf, uc, uc0)
+            self.keep += [uw, ub, uv]
+            up_rec = dict(scope=scope, name=up_name, kind="upflow", src=up_src, dst=up_after[2], w=uw, b=ub, view=uv)
         # (layout = how the fp32 packed matrix is ordered -- what the trainer's index maps and filter gradients use;
         # frag = the split-fp16 copy `w` the forward launch reads is that matrix re-tiled into fragment order)
         self.layers.append(dict(scope=scope, name=name, kind=d.kind, k=k, stride=stride, pad=pad, cin=cin, cout=cout,
                                 act=bool(act), src=src, dst=dst, desc=d, w=wdev, b=bias, cin_pad=cin_pad,
                                 cout_pad=cout_pad, kpad=kpad, layout=layout, tile=tile, kstep=plan.kstep_elems, frag=frag))
+        if up_rec is not None:
+            self.layers.append(up_rec)
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         if kind == "conv" and cout == 2 and k == 3 and stride == 1 and pad == 1:
             kern = f"flow_head_kernel<{tn}>"
@@ -664,8 +679,13 @@ class Engine:
         for i, (lvl, skip_c, dec_c) in enumerate(zip((5, 4, 3, 2), skips, decs)):
             cat = cats[lvl]
             h, w = cat.shape[1], cat.shape[2]
-            self._conv(scope, L[f"deconv{lvl}"], (cur, 0, cur_c), (cat, skip_c, dec_c))
-            if not fused:
+            # without a head lane the upsample_flow of the level rides on the transposed conv's launch (its split-K
+            # finalize pass): one launch less per level on the chain.  FN2_UP_IN_DECONV=0: its own launch (A/B)
+            ride = (not fused and Hd == M and self.heads_as_gemm and self._code(cat) == self.act_code
+                    and bool(int(os.environ.get("FN2_UP_IN_DECONV", "1"))))
+            self._conv(scope, L[f"deconv{lvl}"], (cur, 0, cur_c), (cat, skip_c, dec_c),
+                       up_after=(f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2)) if ride else None)
+            if not fused and not ride:
                 with self._lane(Hd):
                     self._upflow(scope, f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2))
             self._sync(M, Hd)  # concat complete for the main lane's readers (next deconv / interconv)

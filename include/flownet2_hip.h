@@ -188,6 +188,15 @@ typedef struct {
    * element.  NULL: off.  fp32 and split-fp16 outputs, act == FN2_ACT_NONE. */
   const void* act_grad_y;
   int32_t act_grad_c0, act_grad_c1;
+  /* upsample_flowXtoY riding on the transposed conv of the same decoder level (flownet_s.py:57-63: deconvN and
+   * upsample_flow(N+1)toN write neighbouring channel slices of one concat tensor): when up_src is not NULL the call also
+   * writes fn2_upsample_flow(up_src, up_w, up_bias) -- up_src = predict_flow(N+1), dense fp32 [n, out.h/2, out.w/2, 2] --
+   * to channels [up_c0, up_c0 + 2) of out's buffer.  A split-K launch does it in its finalize pass (one launch less on the
+   * decoder chain); any other launch is followed by the stand-alone kernel.  Same values either way.  kind 1 only. */
+  const float* up_src;
+  const float* up_w;     /* [4][4][2][2] HW-O-I */
+  const float* up_bias;  /* [2] or NULL */
+  int32_t up_c0;
 } fn2_conv_desc;
 
 /* How fn2_conv2d runs a layer of this (input dtype, padded Cin, Cout), i.e. how its weight must be packed:

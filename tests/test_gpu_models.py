@@ -466,3 +466,51 @@ def test_model_runs_a_batch_above_the_tensor_limit_in_chunks(monkeypatch):
     net3.load_weights(None, seed=3)
     with pytest.raises(ValueError):
         net3.model({"input_a": a[:2], "input_b": b[:2]})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,shape", [("FlowNetS", (2, 128, 192)), ("FlowNetSD", (1, 64, 128)), ("FlowNetS", (6, 256, 384))])
+def test_upsample_flow_riding_on_the_transposed_conv(model, shape, monkeypatch):
+    """fn2_conv_desc.up_src: without a head lane the engine lets upsample_flow(N+1)toN (flownet_s.py:60-63) ride on the
+    launch of deconvN -- in its split-K finalize pass, or as the stand-alone kernel behind a launch that has none.  Same
+    arithmetic, tap for tap: every prediction equals the plan with the upsample as its own launch bit for bit, and the
+    plan is shorter by the launches that rode."""
+    from src import weights as W
+    from src.engine import Engine
+    n, h, w = shape
+    wts = W.init_weights(model, 77)
+    a, b = images(n, h, w, 9)
+    monkeypatch.setenv("FN2_BRANCHES", "0")   # no head lane: the FlowNet2 stack's setting for its sub-networks
+    monkeypatch.setenv("FN2_UP_IN_DECONV", "0")
+    base = Engine(model, wts, n, h, w, "f16x2")
+    want = {k: v.clone() for k, v in base(a, b).items()}
+    monkeypatch.setenv("FN2_UP_IN_DECONV", "1")
+    eng = Engine(model, wts, n, h, w, "f16x2")
+    got = eng(a, b)
+    rode = [d for d in eng.conv_descs if d.up_src]
+    assert rode and len(eng.ops) == len(base.ops) - len(rode)
+    assert any(bool(eng.lib.fn2_conv2d_workspace_bytes(d)) for d in rode)   # finalize passes did it
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # a launch without split-K (here: the workspace taken away) is followed by the stand-alone kernel: same flow slice
+    import ctypes as C
+    from src import _hip
+    rec = [r for r in eng.layers if r["kind"] == "upflow" and any(d.up_c0 == r["dst"][1] and d.out.data == r["dst"][0].data_ptr()
+                                                                   for d in rode)][0]
+    d = [d for d in rode if d.up_c0 == rec["dst"][1] and d.out.data == rec["dst"][0].data_ptr()][0]
+    buf, c0, _ = rec["dst"]
+    before = buf.clone()
+    raw = buf.view(torch.float32) if buf.dtype != torch.float32 else buf
+    g0 = c0 // 8 * 8
+    raw[..., g0:g0 + 8] = 0          # the 8-channel group holding the two flow channels (split fp16: hi / lo halves)
+    ws, wsb = d.workspace, d.workspace_bytes
+    d.workspace, d.workspace_bytes = None, 0
+    _hip.check(eng.lib.fn2_conv2d(C.byref(d), _hip.stream_ptr()))
+    d.workspace, d.workspace_bytes = ws, wsb
+    torch.cuda.synchronize()
+    assert torch.equal(buf.view(torch.float32)[..., g0:g0 + 8], before.view(torch.float32)[..., g0:g0 + 8])
+    eng.capture()
+    eng(a, b)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(eng.outputs[k], want[k]), k
