@@ -395,42 +395,9 @@ __global__ void __launch_bounds__(256) flow_head_kernel(const ConvArgs p) {
       // block per pixel (small maps: the 6x8 .. 24x32 levels, 192..3072 pixels at batch 4): the four waves split the
       // 9 x C/8 items of the pixel and the partial sums meet in LDS -- four times the loads in flight per pixel of
       // the wave-per-pixel form below, whose single wave walks up to 18 dependent iterations
-      __shared__ float part[4][2];
-      const int wv = threadIdx.x >> 6;
-      for (long m = blockIdx.x; m < p.M; m += gridDim.x) {
-        const int x = (int)(m % p.W), y = (int)((m / p.W) % p.H);
-        const size_t nb = (size_t)(m / p.W / p.H) * p.H * p.W;
-        float a0 = 0.f, a1 = 0.f;
-        for (int q = threadIdx.x; q < nitems; q += 256) {
-          const int tap = q / groups, gi = q - tap * groups;
-          const int ky = tap / 3, kx = tap - ky * 3;
-          const int iy = y + ky - 1, ix = x + kx - 1;
-          if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
-          const uint4* src = reinterpret_cast<const uint4*>(in + (nb + (size_t)iy * p.W + ix) * p.in_cs + p.in_c0 + gi * 8);
-          float xv[8];
-          join8(src[0], src[1], xv);
-          const float* u = wf0 + (size_t)q * 8;
-          const float* v = wf1 + (size_t)q * 8;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            a0 += xv[j] * u[j];
-            a1 += xv[j] * v[j];
-          }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          a0 += __shfl_xor(a0, off, 64);
-          a1 += __shfl_xor(a1, off, 64);
-        }
-        if (lane == 0) { part[wv][0] = a0; part[wv][1] = a1; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          float* po = out + (size_t)m * p.out_cs + p.out_c0;
-          po[0] = (part[0][0] + part[1][0] + part[2][0] + part[3][0]) * p.out_scale + (p.bias ? p.bias[0] : 0.f);
-          po[1] = (part[0][1] + part[1][1] + part[2][1] + part[3][1]) * p.out_scale + (p.bias ? p.bias[1] : 0.f);
-        }
-        __syncthreads();
-      }
+      __shared__ float part[8];
+      for (long m = blockIdx.x; m < p.M; m += gridDim.x)
+        fh_pixel(in, p.H, p.W, p.in_cs, p.in_c0, groups, wf0, wf1, p.bias, p.out_scale, out + (size_t)m * p.out_cs + p.out_c0, m, part);
       return;
     }
     for (long m = wave; m < p.M; m += nwaves) {
@@ -591,6 +558,10 @@ __global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __re
   }
 }
 
+// Where a tail reads its partials: one tensor [pixel][t_cs], or the `nslab` raw split-K slabs of the GEMM that made them
+// (slab stride in floats; their sum, in split order, times `scale` is what the finalize pass would have stored).
+struct TailSrc { const float* t; int t_cs; int nslab; long slab; float scale; };
+
 // Flow-head tail in ONE launch: the gather above generalised to NT x NT taps (3: predict_flowN; 5: a linear interconvN
 // composed with its predict_flowN, see fn2_flow_head_tail in flownet2_hip.h) and followed, in the same block, by
 // upsample_flowXtoY (4x4 stride-2 transposed conv on the two flow channels, flownet_s.py:60-63) into the 2-channel
@@ -602,7 +573,7 @@ __global__ void __launch_bounds__(256) flow_head_gather_kernel(const float* __re
 // border pixels use other weights) -- it is read from there instead of being gathered.
 // Tap order of the sums = the existing kernels': ky outer, kx inner from the bias; ty outer, tx inner for the upsample.
 template <int NT, int TY, int TX, bool UP, typename OutT>
-__global__ void __launch_bounds__(256) head_tail_kernel(const float* __restrict__ t, int t_cs, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256) head_tail_kernel(const TailSrc ts, const float* __restrict__ bias,
                                                         float* __restrict__ pf, int N, int H, int W, int ring,
                                                         const float* __restrict__ up_w, const float* __restrict__ up_bias,
                                                         OutT* __restrict__ up, int up_cs, int up_c0) {
@@ -624,8 +595,15 @@ __global__ void __launch_bounds__(256) head_tail_kernel(const float* __restrict_
       const int hy = p / RW, hx = p - hy * RW;
       const int gy = y0 + hy, gx = x0 + hx;
       float2 v = make_float2(0.f, 0.f);
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = *reinterpret_cast<const float2*>(t + (((long)n * H + gy) * W + gx) * t_cs + 2 * j);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const float* src = ts.t + (((long)n * H + gy) * W + gx) * ts.t_cs + 2 * j;
+        v = *reinterpret_cast<const float2*>(src);
+        for (int sl = 1; sl < ts.nslab; ++sl) {   // raw split-K slabs of the head GEMM (fn2_conv_desc.raw_partials): summed in split order
+          const float2 u = *reinterpret_cast<const float2*>(src + sl * ts.slab);
+          v.x += u.x; v.y += u.y;
+        }
+        v.x *= ts.scale; v.y *= ts.scale;
+      }
       sm[idx] = v;
     }
     __syncthreads();
@@ -886,29 +864,29 @@ static int pack_imgs(const float* i0, const float* i1, const fn2_tensor* out, in
 }
 
 template <int NT, int TY, int TX, typename OutT>
-void launch_head_tail(bool up, const float* t, int t_cs, const float* bias, float* pf, int n, int h, int w, int ring,
+void launch_head_tail(bool up, const TailSrc ts, const float* bias, float* pf, int n, int h, int w, int ring,
                       const float* up_w, const float* up_bias, void* up_data, int up_cs, int up_c0, hipStream_t s) {
   const long tiles = (long)n * ((h + TY - 1) / TY) * ((w + TX - 1) / TX);
   const dim3 grid((unsigned)std::min<long>(tiles, 1 << 16)), block(256);
   if (up)
-    hipLaunchKernelGGL((head_tail_kernel<NT, TY, TX, true, OutT>), grid, block, 0, s, t, t_cs, bias, pf, n, h, w, ring, up_w,
+    hipLaunchKernelGGL((head_tail_kernel<NT, TY, TX, true, OutT>), grid, block, 0, s, ts, bias, pf, n, h, w, ring, up_w,
                        up_bias, (OutT*)up_data, up_cs, up_c0);
   else
-    hipLaunchKernelGGL((head_tail_kernel<NT, TY, TX, false, float>), grid, block, 0, s, t, t_cs, bias, pf, n, h, w, ring,
+    hipLaunchKernelGGL((head_tail_kernel<NT, TY, TX, false, float>), grid, block, 0, s, ts, bias, pf, n, h, w, ring,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, 0);
 }
 template <typename OutT>
-void launch_head_tail_t(int taps, bool up, const float* t, int t_cs, const float* bias, float* pf, int n, int h, int w,
+void launch_head_tail_t(int taps, bool up, const TailSrc ts, const float* bias, float* pf, int n, int h, int w,
                         int ring, const float* up_w, const float* up_bias, void* up_data, int up_cs, int up_c0,
                         hipStream_t s) {
   // big maps: 8-row tiles (less halo per flow pixel); small ones: 4 x 32 tiles so that a 48 x 64 level still has ~100 blocks
   const long big = (long)n * ((h + 7) / 8) * ((w + 63) / 64);
   if (taps == 3) {
-    if (big >= 256) launch_head_tail<3, 8, 64, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
-    else launch_head_tail<3, 4, 32, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+    if (big >= 256) launch_head_tail<3, 8, 64, OutT>(up, ts, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+    else launch_head_tail<3, 4, 32, OutT>(up, ts, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
   } else {
-    if (big >= 256) launch_head_tail<5, 8, 32, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
-    else launch_head_tail<5, 4, 32, OutT>(up, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+    if (big >= 256) launch_head_tail<5, 8, 32, OutT>(up, ts, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
+    else launch_head_tail<5, 4, 32, OutT>(up, ts, bias, pf, n, h, w, ring, up_w, up_bias, up_data, up_cs, up_c0, s);
   }
 }
 
@@ -1009,6 +987,7 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
   if (d->out.dtype == FN2_F16X2) FN2_REQUIRE(d->out.cs % 8 == 0 && d->out.c0 % 8 == 0, "conv2d: split-fp16 views are group (8) aligned");
 
   ConvArgs& a = *out;
+  a = ConvArgs{};   // (optional parts -- head blocks, ring blocks -- are off unless a caller sets them afterwards)
   a.KH_KW_hint = 0;
   a.wfrag = wfrag ? 1 : 0;   // (2 = the 3-slot ring form, chosen below)
   a.merged = d->kind == 5 ? 1 : 0;
@@ -1256,6 +1235,21 @@ int64_t fn2_conv2d_workspace_bytes(const fn2_conv_desc* d) {
   return s > 1 ? split_bytes(a, s) : 0;
 }
 
+int fn2_conv2d_splits(const fn2_conv_desc* d) {
+  ConvArgs a;
+  int tile, phases;
+  if (build_args(d, &a, &tile, &phases) != FN2_OK || is_flow_head(d)) return 1;
+  int sk = preferred_split(a, tile, phases);
+  while (sk > 1 && (d->workspace == nullptr || split_bytes(a, sk) > d->workspace_bytes)) --sk;
+  if ((long)a.N * a.out_H * a.out_W * a.ws_cs >= (1L << 31)) sk = 1;
+  if (sk > 1) {   // as fn2_conv2d rounds it: whole stages, no empty split
+    const int kper = cdiv(a.ksteps, sk);
+    sk = cdiv(a.ksteps, kper);
+    if (d->wgt_layout >= 1) sk = cdiv(a.ksteps / 2, cdiv(kper, 2));
+  }
+  return sk < 1 ? 1 : sk;
+}
+
 int fn2_conv2d_kernel_name(const fn2_conv_desc* d, char* name, int cap) {
   FN2_REQUIRE(name && cap > 0, "conv2d_kernel_name: no buffer");
   name[0] = 0;
@@ -1302,6 +1296,35 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     a.splitk = sk;
     a.ws = reinterpret_cast<float*>(d->workspace);
   }
+  if (d->head != nullptr && !conv_name_sink().buf) {
+    // fn2_conv_desc.head: ride on this launch when it is the split-K split-fp16 launch on fragment-order weights (conv2.hip:
+    // the head pixels are extra z slices of its grid), else run in front of it
+    const fn2_conv_desc* h = reinterpret_cast<const fn2_conv_desc*>(d->head);
+    FN2_REQUIRE(d->kind == 1 && is_flow_head(h) && h->head == nullptr && h->up_src == nullptr,
+                "conv2d: head rides on a kind-1 transposed conv and is a 3x3 two-output fp32 flow head");
+    FN2_REQUIRE(h->in.data == d->in.data && h->in.n == d->in.n && h->in.h == d->in.h && h->in.w == d->in.w &&
+                    h->in.cs == d->in.cs && h->in.c0 == d->in.c0 && h->in.dtype == d->in.dtype,
+                "conv2d: head and transposed conv must read the same view");
+    ConvArgs ha;
+    int htile, hphases;
+    rc = build_args(h, &ha, &htile, &hphases);
+    if (rc) return rc;
+    const char* e = getenv("FN2_HEAD_RIDE");
+    const bool ride = d->in.dtype == FN2_F16X2 && d->wgt_layout == 2 && tile == 128 && sk > 1 && !(e && atoi(e) == 0);
+    if (ride) {
+      a.fh_M = ha.M;
+      a.fh_w = reinterpret_cast<const float*>(ha.wgt);
+      a.fh_w1 = ha.ksteps * 4 * 4;          // floats per output plane (flow_head_kernel: ksteps * 4 chunks of 4 floats)
+      a.fh_groups = ha.cin_chunks >> 1;
+      a.fh_bias = ha.bias;
+      a.fh_out = reinterpret_cast<float*>(ha.out);
+      a.fh_out_cs = ha.out_cs; a.fh_out_c0 = ha.out_c0;
+      a.fh_scale = ha.out_scale;
+    } else {
+      rc = fn2_conv2d(h, stream);
+      if (rc) return rc;
+    }
+  }
   if (d->wgt_layout >= 1) {
     // LDS-DMA kernel: a stage is two generic k-steps (the tap never changes inside a stage)
     a.ksteps = a.ksteps / 2;
@@ -1323,7 +1346,7 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     uv.c = 2; uv.c0 = d->up_c0;
     return fn2_upsample_flow(d->up_src, d->up_w, d->up_bias, &uv, d->out.n, d->out.h / 2, d->out.w / 2, stream);
   }
-  if (a.dbg & 524288) return rc;  // (524288: ablation, no finalize pass)
+  if ((a.dbg & 524288) || d->raw_partials) return rc;  // (524288: ablation, no finalize pass; raw_partials: the caller sums the slabs)
   const long npix = (long)a.N * a.out_H * a.out_W;
   const int fgrid = grid_for(npix * (a.ws_cs / 4 + (d->up_src != nullptr ? 1 : 0)), 256);
   if (d->out.dtype == FN2_F32)
@@ -1358,7 +1381,15 @@ int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out
 
 int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, float* pf, int n, int h, int w, int ring,
                        const float* up_w, const float* up_bias, const fn2_tensor* up_out, void* stream) {
+  return fn2_flow_head_tail_slabs(t, t_cs, 1, 0, 1.f, taps, bias, pf, n, h, w, ring, up_w, up_bias, up_out, stream);
+}
+
+int fn2_flow_head_tail_slabs(const float* t, int t_cs, int nslab, int64_t slab_stride, float scale, int taps, const float* bias,
+                             float* pf, int n, int h, int w, int ring, const float* up_w, const float* up_bias,
+                             const fn2_tensor* up_out, void* stream) {
   FN2_REQUIRE(t && pf, "flow_head_tail: null pointer");
+  FN2_REQUIRE(nslab >= 1 && (nslab == 1 || slab_stride >= (int64_t)n * h * w * t_cs), "flow_head_tail: bad slab geometry");
+  const TailSrc ts{t, t_cs, nslab, (long)slab_stride, scale};
   FN2_REQUIRE(taps == 3 || taps == 5, "flow_head_tail: taps must be 3 or 5");
   FN2_REQUIRE(t_cs >= 2 * taps * taps && t_cs % 2 == 0 && n >= 1 && h >= 1 && w >= 1,
               "flow_head_tail: t must hold 2 * taps^2 partials per pixel");
@@ -1366,7 +1397,7 @@ int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, fl
   const bool up = up_w != nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (!up) {
-    launch_head_tail_t<float>(taps, false, t, t_cs, bias, pf, n, h, w, ring, nullptr, nullptr, nullptr, 0, 0, s);
+    launch_head_tail_t<float>(taps, false, ts, bias, pf, n, h, w, ring, nullptr, nullptr, nullptr, 0, 0, s);
   } else {
     int rc = check_view(up_out, "flow_head_tail upsample output");
     if (rc) return rc;
@@ -1374,10 +1405,10 @@ int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, fl
                 "flow_head_tail: the upsample view must be [n, 2h, 2w, 2]");
     if (up_out->dtype == FN2_F16X2) FN2_REQUIRE(up_out->c0 % 2 == 0, "flow_head_tail: split-fp16 slice must start at an even channel");
     void* d = up_out->data;
-    if (up_out->dtype == FN2_F32) launch_head_tail_t<float>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
-    else if (up_out->dtype == FN2_F16X2) launch_head_tail_t<x2_t>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
-    else if (up_out->dtype == FN2_BF16) launch_head_tail_t<bf16_t>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
-    else launch_head_tail_t<f16_t>(taps, true, t, t_cs, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+    if (up_out->dtype == FN2_F32) launch_head_tail_t<float>(taps, true, ts, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+    else if (up_out->dtype == FN2_F16X2) launch_head_tail_t<x2_t>(taps, true, ts, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+    else if (up_out->dtype == FN2_BF16) launch_head_tail_t<bf16_t>(taps, true, ts, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
+    else launch_head_tail_t<f16_t>(taps, true, ts, bias, pf, n, h, w, ring, up_w, up_bias, d, up_out->cs, up_out->c0, s);
   }
   FN2_CHECK_LAUNCH("flow_head_tail");
   return FN2_OK;

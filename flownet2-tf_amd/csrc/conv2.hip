@@ -219,6 +219,19 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
       return;
     }
   }
+  if constexpr (WREG && SLAB && is_x2<T>::value) {
+    if (p.fh_M > 0 && (int)blockIdx.z >= p.fh_z0) {
+      // predict_flow(N+1) riding on deconvN (fn2_conv_desc.head): the z slices behind the convolution's own are head
+      // blocks, a pixel at a time each (they are dispatched last and fill the slots the convolution leaves free)
+      float* part = reinterpret_cast<float*>(lds0_all);
+      const long e = (((long)blockIdx.z - p.fh_z0) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const long total = (long)(gridDim.z - p.fh_z0) * gridDim.y * gridDim.x;
+      for (long m = e; m < p.fh_M; m += total)
+        fh_pixel(reinterpret_cast<const x2_t*>(p.in), p.H, p.W, p.in_cs, p.in_c0, p.fh_groups, p.fh_w, p.fh_w + p.fh_w1,
+                 p.fh_bias, p.fh_scale, p.fh_out + (size_t)m * p.fh_out_cs + p.fh_out_c0, m, part);
+      return;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = KG > 1 ? wave_all >> 2 : 0;   // K group of this wave
@@ -1682,6 +1695,18 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
       } else {
         dim3 grid(cdiv(a.M, 64), a.cout_pad / 128, z);
         const bool slab = a.splitk > 1;
+        ConvArgs ah = a;
+        if (a.fh_M > 0 && slab && !conv_name_sink().buf) {
+          // head pixels as extra z slices: about FN2_FH_BLOCKS (1024; 256: +30 us, 512: +10 us on FlowNet2 b4) blocks, a pixel at a time each
+          const char* e = getenv("FN2_FH_BLOCKS");
+          const long per_z = (long)grid.x * grid.y;
+          const long want = std::min<long>(a.fh_M, e ? atoi(e) : 1024);
+          ah.fh_z0 = z;
+          grid.z = z + (unsigned)std::max<long>(1, (want + per_z - 1) / per_z);
+        } else {
+          ah.fh_M = 0;
+        }
+        const ConvArgs& a = ah;   // (the launches below take the copy)
         if (conv_name_sink().buf)
           snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_igemm2_kernel<%s, %s, 4, 1, 1, 2, %d, 1, false, true, %s>",
                    type_name<T>(), type_name<OutT>(), a.wfrag == 2 ? 3 : 2, slab ? "true" : "false");

@@ -32,6 +32,15 @@ struct ConvArgs {
   const float* h5_wc;         //     fp32 [9 cases][25 taps][8 h5_groups][2]
   const float* h5_bc;         //     fp32 [9][2]
   int h5_rows;                // strip form (head5_strip_kernel): h5_tx = strips of 60 output columns, h5_ty = row segments, h5_rows = output rows per segment
+  // predict_flow(N+1) riding on the transposed conv of level N (fn2_conv_desc.head; conv2.hip, the WREG SLAB launch): both read
+  // the same concat buffer.  Blocks with blockIdx.z >= fh_z0 compute head pixels (block per pixel, fh_pixel below).
+  int fh_M, fh_z0;            // head pixels N * H * W (0: nothing rides); first z slice of the head part of the grid
+  const float* fh_w;          // the head's fp32 weight: [o][tap][8 * fh_groups], plane o = 1 at + fh_w1 floats
+  int fh_w1, fh_groups;
+  const float* fh_bias;       // [2] or nullptr
+  float* fh_out;              // fp32 view [n, h, w, fh_out_cs] + fh_out_c0
+  int fh_out_cs, fh_out_c0;
+  float fh_scale;
   int wfrag;    // 1: the weight is stored in MFMA-fragment order (wgt_layout 2) and loaded straight into registers (conv2.hip, WREG)
   int accum;    // 1: out += result (fp32 outputs; gradient accumulation into shared buffers)
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0
@@ -45,6 +54,48 @@ struct ConvArgs {
   int mask_c0, mask_c1;  // ... applied to channels [mask_c0, mask_c1) of the output view
   int dbg;     // FN2_CONV_DBG ablation bits (timing experiments only; results are wrong when set)
 };
+
+// One pixel of a 3x3 two-output flow head on a split-fp16 input, by one block of 256 threads: the four waves split the
+// 9 x C/8 (tap, 8-channel group) items, partial sums meet in `part` (8 floats of LDS).  flow_head_kernel's block-per-pixel
+// form (conv.hip) and the head blocks of a transposed conv's launch (conv2.hip) are this function.
+__device__ __forceinline__ void fh_pixel(const x2_t* __restrict__ in, int H, int W, int in_cs, int in_c0, int groups,
+                                         const float* __restrict__ wf0, const float* __restrict__ wf1,
+                                         const float* __restrict__ bias, float out_scale, float* __restrict__ po, long m,
+                                         float* part) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nitems = 9 * groups;
+  const int x = (int)(m % W), y = (int)((m / W) % H);
+  const size_t nb = (size_t)(m / W / H) * H * W;
+  float a0 = 0.f, a1 = 0.f;
+  for (int q = threadIdx.x; q < nitems; q += 256) {
+    const int tap = q / groups, gi = q - tap * groups;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = y + ky - 1, ix = x + kx - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const uint4* src = reinterpret_cast<const uint4*>(in + (nb + (size_t)iy * W + ix) * in_cs + in_c0 + gi * 8);
+    float xv[8];
+    join8(src[0], src[1], xv);
+    const float* u = wf0 + (size_t)q * 8;
+    const float* v = wf1 + (size_t)q * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 += xv[j] * u[j];
+      a1 += xv[j] * v[j];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_xor(a0, off, 64);
+    a1 += __shfl_xor(a1, off, 64);
+  }
+  if (lane == 0) { part[wv * 2] = a0; part[wv * 2 + 1] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    po[0] = (part[0] + part[2] + part[4] + part[6]) * out_scale + (bias ? bias[0] : 0.f);
+    po[1] = (part[1] + part[3] + part[5] + part[7]) * out_scale + (bias ? bias[1] : 0.f);
+  }
+  __syncthreads();
+}
 
 // Backward of LeakyReLU fused into the epilogue of the layer that completes a gradient slice: x is the finished
 // gradient wrt the activation OUTPUT at `elem`; the factor d/dx (0.55 x + 0.45 |x|) is read off the forward output y at

@@ -34,7 +34,8 @@ class Fn2ConvDesc(C.Structure):
                 ("pad", C.c_int32), ("act", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
                 ("kpad", C.c_int32), ("wgt_layout", C.c_int32), ("accumulate", C.c_int32), ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("act_grad_y", C.c_void_p), ("act_grad_c0", C.c_int32), ("act_grad_c1", C.c_int32),
-                ("up_src", C.c_void_p), ("up_w", C.c_void_p), ("up_bias", C.c_void_p), ("up_c0", C.c_int32)]
+                ("up_src", C.c_void_p), ("up_w", C.c_void_p), ("up_bias", C.c_void_p), ("up_c0", C.c_int32),
+                ("head", C.c_void_p), ("raw_partials", C.c_int32)]
 
 
 class Fn2BwdwDesc(C.Structure):
@@ -70,11 +71,13 @@ PROTOTYPES = {
     "fn2_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(Fn2ConvDesc)]),
     "fn2_conv2d": (_i, [C.POINTER(Fn2ConvDesc), _p]),
     "fn2_conv2d_kernel_name": (_i, [C.POINTER(Fn2ConvDesc), C.c_char_p, _i]),
+    "fn2_conv2d_splits": (_i, [C.POINTER(Fn2ConvDesc)]),
     "fn2_augment_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fn2_flow_augmentation_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fn2_flow_head_gather": (_i, [_p, _i, _p, _p, _i, _i, _i, _p]),
     "fn2_upsample_flow": (_i, [_p, _p, _p, _tp, _i, _i, _i, _p]),
     "fn2_flow_head_tail": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _tp, _p]),
+    "fn2_flow_head_tail_slabs": (_i, [_p, _i, _i, C.c_int64, _f, _i, _p, _p, _i, _i, _i, _i, _p, _p, _tp, _p]),
     "fn2_flow_head_ring": (_i, [_tp, _p, _p, _p, _p]),
     "fn2_flow_head5": (_i, [_tp, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p]),
     "fn2_u8_to_f32_lut": (_i, [_p, _p, _p, C.c_int64, _p]),

@@ -174,7 +174,10 @@ class Engine:
         # head (_composed_head).  Inference engines only (the trainer needs both variables); FN2_COMPOSE=0: off (A/B).
         self.compose_heads = bool(heads_as_gemm) and dtype == "f16x2" and bool(int(os.environ.get("FN2_COMPOSE", "1")))
         self._head_t = None
+        self._own_ws = set()        # descriptors that keep a split-K workspace of their own (_head_slabs)
+        self._pending_head = None   # a plain flow head waiting for the transposed conv that takes it along (_conv: defer_head)
         self.outputs = self._build()
+        assert self._pending_head is None
         self._check_variables(strict)
         self._alloc_workspace()
         self._resolve_kernel_names()
@@ -280,12 +283,14 @@ class Engine:
         self.branch_of.append(self._branch)
 
     # ------------------------------------------------------------------ layers
-    def _conv(self, scope, spec, src, dst, up=None, up_after=None):
+    def _conv(self, scope, spec, src, dst, up=None, up_after=None, defer_head=False):
         """src/dst: (buffer, c0, c).  One fn2_conv2d launch.  up (flow heads only): (name of the upsample_flowXtoY layer
         that follows the head, its destination slice) -- returns True when that upsample was fused into the head's tail
         launch (the caller then emits no fn2_upsample_flow for it).  up_after (transposed convs only): (layer name,
         predict_flow(N+1) buffer, destination slice) of the upsample_flow(N+1)toN that writes the neighbouring slice of
-        the same concat buffer: it rides on this launch (fn2_conv_desc.up_src: the split-K finalize pass does it)."""
+        the same concat buffer: it rides on this launch (fn2_conv_desc.up_src: the split-K finalize pass does it).
+        defer_head (plain flow heads only): build the launch but do not emit it -- the next transposed conv, which reads the
+        same tensor, takes it along (fn2_conv_desc.head)."""
         name, kind, k, stride, pad, cin, cout, act = spec
         sbuf, sc0, sc = src
         dbuf, dc0, dc = dst
@@ -351,6 +356,11 @@ class Engine:
         self.conv_descs.append(d)
         self.desc_branch.append(self._branch)
         up_rec = None
+        if self._pending_head is not None and kind != "conv":
+            hd = self._pending_head
+            assert up_after is not None and hd.inp.data == d.inp.data and hd.inp.c0 == d.inp.c0, (scope, name)
+            d.head = C.addressof(hd)
+            self._pending_head = None
         if up_after is not None:
             assert kind != "conv" and not merged
             up_name, up_src, (ubuf, uc0, uc) = up_after
@@ -379,13 +389,35 @@ class Engine:
             shape = {128: "4, 2, 2", 64: "4, 1, 4", 32: "2, 1, 4", 16: "1, 1, 4"}[tile]
             on = _TNAME[self.dtype_name] if self._code(dbuf) == self.act_code else "float"
             kern = f"conv_igemm_kernel<{tn}, {on}, {shape}>"
-        self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d), kernel=kern)
+        if defer_head and kern.startswith("flow_head_kernel"):
+            assert self._pending_head is None
+            self._pending_head = d
+        else:
+            self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d), kernel=kern)
         n, oh, ow = dbuf.shape[0], dbuf.shape[1], dbuf.shape[2]
         taps = k * k if kind == "conv" else 4
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * oh * ow * taps * cin * cout))
         osz = 4 if dbuf.dtype == torch.float32 else 2
         self.layer_io_bytes.append((f"{scope}/{name}", float(sbuf.shape[0] * sbuf.shape[1] * sbuf.shape[2] * cin * esz
                                                             + n * oh * ow * cout * osz + k * k * cin * cout * esz)))
+
+    def _head_slabs(self, d, head_t, t_cs):
+        """Where the tail of a GEMM-form head finds its partials: (pointer, t_cs, slabs, slab stride, scale).  A head GEMM
+        that splits K keeps its raw slabs (fn2_conv_desc.raw_partials, in a workspace of its own) and the tail sums them:
+        no finalize launch between the two.  FN2_HEAD_SLABS=0: the finalize pass writes head_t as before (A/B)."""
+        need = int(self.lib.fn2_conv2d_workspace_bytes(C.byref(d)))
+        if need <= 0 or not int(os.environ.get("FN2_HEAD_SLABS", "1")):
+            return _hip.ptr(head_t), t_cs, 1, 0, 1.0
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        d.workspace, d.workspace_bytes, d.raw_partials = ws.data_ptr(), need, 1
+        self.keep.append(ws)
+        self._own_ws.add(C.addressof(d))
+        splits = int(self.lib.fn2_conv2d_splits(C.byref(d)))
+        if splits <= 1:
+            d.raw_partials = 0
+            return _hip.ptr(head_t), t_cs, 1, 0, 1.0
+        ws_cs = (d.out.c + 3) // 4 * 4
+        return ws.data_ptr(), ws_cs, splits, d.out.n * d.out.h * d.out.w * ws_cs, float(d.out_scale) or 1.0
 
     def _wants_fragments(self, d):
         """True when the library would run this layer on the plain two-stage 128 x 64 instantiation (no ring, K groups,
@@ -446,6 +478,7 @@ class Engine:
         tn = _TNAME[self.dtype_name] if in_code == self.act_code else "float"
         self._op(f"{scope}/{name}", self.lib.fn2_conv2d, C.byref(d),
                  kernel=f"conv_igemm2_kernel<{tn}, float, {conv2_kernel_args(plan.cout_tile, 0, cout_pad, 1, tn == 'fn2::x2_t')}>")
+        t_ptr, t_cs, nslab, slab, tscale = self._head_slabs(d, head_t, 32)
         if up is not None and int(os.environ.get("FN2_FUSE_UPFLOW", "1")):
             up_name, (ubuf, uc0, uc) = up
             uw = W.to_device(self._w(f"{scope}/{up_name}/weights"), torch.float32, self.device)  # [4,4,2,2] HW-O-I
@@ -453,11 +486,11 @@ class Engine:
             uv = self._v(ubuf, uc, uc0)
             self.keep += [uw, ub, uv]
             self.layers.append(dict(scope=scope, name=up_name, kind="upflow", src=pf, dst=up[1], w=uw, b=ub, view=uv))
-            self._op(f"{scope}/{name}/tail+{up_name}", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 32, 3,
-                     _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd, 0, _hip.ptr(uw),
+            self._op(f"{scope}/{name}/tail+{up_name}", self.lib.fn2_flow_head_tail_slabs, t_ptr, t_cs, nslab, slab,
+                     C.c_float(tscale), 3, _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd, 0, _hip.ptr(uw),
                      _hip.ptr(ub) if ub is not None else None, C.byref(uv), kernel="flow_head_tail")
         else:
-            self._op(f"{scope}/{name}/tail", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 32, 3,
+            self._op(f"{scope}/{name}/tail", self.lib.fn2_flow_head_tail_slabs, t_ptr, t_cs, nslab, slab, C.c_float(tscale), 3,
                      _hip.ptr(bias) if bias is not None else None, _hip.ptr(pf), n, h, wd, 0, None, None, None,
                      kernel="flow_head_tail")
         self.layer_flops.append((f"{scope}/{name}", 2.0 * n * h * wd * 9 * cin * 2))
@@ -542,6 +575,7 @@ class Engine:
         self.conv_descs.append(d)
         self.desc_branch.append(self._branch)
         self._op(f"{scope}/{ic_name}+{pf_name}", self.lib.fn2_conv2d, C.byref(d), kernel="conv_igemm2_kernel (composed head)")
+        t_ptr, t_cs, nslab, slab, tscale = self._head_slabs(d, head_t, 64)
         if up is not None:
             up_name, (ubuf, uc0, uc) = up
             uw = W.to_device(self._w(f"{scope}/{up_name}/weights"), torch.float32, self.device)
@@ -549,12 +583,12 @@ class Engine:
             uv = self._v(ubuf, uc, uc0)
             self.keep += [uw, ub, uv]
             self.layers.append(dict(scope=scope, name=up_name, kind="upflow", src=pf, dst=up[1], w=uw, b=ub, view=uv))
-            self._op(f"{scope}/{pf_name}/tail+{up_name}", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 64, 5, _hip.ptr(b5),
-                     _hip.ptr(pf), n, h, wd, 1, _hip.ptr(uw), _hip.ptr(ub) if ub is not None else None, C.byref(uv),
-                     kernel="flow_head_tail")
+            self._op(f"{scope}/{pf_name}/tail+{up_name}", self.lib.fn2_flow_head_tail_slabs, t_ptr, t_cs, nslab, slab,
+                     C.c_float(tscale), 5, _hip.ptr(b5), _hip.ptr(pf), n, h, wd, 1, _hip.ptr(uw),
+                     _hip.ptr(ub) if ub is not None else None, C.byref(uv), kernel="flow_head_tail")
         else:
-            self._op(f"{scope}/{pf_name}/tail", self.lib.fn2_flow_head_tail, _hip.ptr(head_t), 64, 5, _hip.ptr(b5), _hip.ptr(pf),
-                     n, h, wd, 1, None, None, None, kernel="flow_head_tail")
+            self._op(f"{scope}/{pf_name}/tail", self.lib.fn2_flow_head_tail_slabs, t_ptr, t_cs, nslab, slab, C.c_float(tscale), 5,
+                     _hip.ptr(b5), _hip.ptr(pf), n, h, wd, 1, None, None, None, kernel="flow_head_tail")
         # algorithmic work = what the reference graph does (two 3x3 convolutions), whatever form executes it
         self.layer_flops.append((f"{scope}/{ic_name}+{pf_name}", 2.0 * n * h * wd * 9 * (sc * cm + cm * 2)))
         self.layer_io_bytes.append((f"{scope}/{ic_name}+{pf_name}", float(n * h * wd * (sc * 4 + 2 * 4) + 9 * (sc * cm + 2 * cm) * 4)))
@@ -651,7 +685,7 @@ class Engine:
         branches = self.desc_branch + [0] * (len(self.conv_descs) - len(self.desc_branch))  # the trainer appends descs
         self.workspace = {}
         for br in sorted(set(branches)):
-            descs = [d for d, b in zip(self.conv_descs, branches) if b == br]
+            descs = [d for d, b in zip(self.conv_descs, branches) if b == br and C.addressof(d) not in self._own_ws]
             need = max([int(self.lib.fn2_conv2d_workspace_bytes(C.byref(d))) for d in descs] + [0])
             if need > 0:
                 self.workspace[br] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
@@ -670,10 +704,14 @@ class Engine:
         pf = self._buf(f"{tag}/predict_flow6", N, h, w, 2, torch.float32)
         self._sync(Hd, M)  # conv6_1 is there
         skips, decs = (512, 512, 256, 128), (512, 256, 128, 64)
+        # without a head lane a plain flow head rides on the transposed conv that follows it (same input tensor) and its
+        # upsample_flow on that launch's finalize pass: the level is ONE fn2_conv2d call.  FN2_HEAD_IN_DECONV=0: off (A/B)
+        ride_heads = (Hd == M and self.heads_as_gemm and self.dtype_name == "f16x2"
+                      and bool(int(os.environ.get("FN2_UP_IN_DECONV", "1"))) and bool(int(os.environ.get("FN2_HEAD_IN_DECONV", "1"))))
         with self._lane(Hd):
             # (a GEMM-form head takes the upsample_flow that follows it into its tail launch)
             fused = self._conv(scope, L["predict_flow6"], (c6_1, 0, 1024), (pf, 0, 2),
-                               up=("upsample_flow6to5", (cats[5], skips[0] + decs[0], 2)))
+                               up=("upsample_flow6to5", (cats[5], skips[0] + decs[0], 2)), defer_head=ride_heads)
         preds["predict_flow6"] = pf
         cur, cur_c = c6_1, 1024
         for i, (lvl, skip_c, dec_c) in enumerate(zip((5, 4, 3, 2), skips, decs)):
@@ -711,7 +749,8 @@ class Engine:
                 self._sync(Hd, M)
                 head_src = (ic, 0, dec_c)
             with self._lane(Hd):
-                fused = self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2), up=up)
+                fused = self._conv(scope, L[f"predict_flow{lvl}"], head_src, (pf, 0, 2), up=up,
+                                   defer_head=ride_heads and lvl > 2 and not interconv)
             preds[f"predict_flow{lvl}"] = pf
         return preds
 

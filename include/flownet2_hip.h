@@ -197,6 +197,16 @@ typedef struct {
   const float* up_w;     /* [4][4][2][2] HW-O-I */
   const float* up_bias;  /* [2] or NULL */
   int32_t up_c0;
+  /* predict_flow(N+1) riding on the same launch (flownet_s.py:54-59: the head and deconvN read the same tensor): `head` is
+   * the complete descriptor of a 3x3 two-output fp32 flow head (kind 0, k 3, s 1, p 1, no activation) whose `in` view is
+   * this descriptor's `in` view.  The call computes it as well, BEFORE up_src is read (so up_src may be head->out.data):
+   * as extra blocks of a split-K split-fp16 launch on fragment-order weights, else as fn2_conv2d(head) in front of this
+   * launch.  Same values either way.  kind 1 only; NULL: off. */
+  const void* head;      /* const fn2_conv_desc* */
+  /* 1: a launch that splits K leaves its S raw fp32 partial-sum slabs in `workspace` -- [S][n*h*w][round_up(Cout, 4)], no
+   * bias, no out_scale -- and writes nothing to `out`: the consumer sums them (fn2_flow_head_tail_slabs does, for the
+   * GEMM-form flow heads: one launch less per head).  S = fn2_conv2d_splits(desc); with S == 1 the call is the ordinary one. */
+  int32_t raw_partials;
 } fn2_conv_desc;
 
 /* How fn2_conv2d runs a layer of this (input dtype, padded Cin, Cout), i.e. how its weight must be packed:
@@ -222,6 +232,8 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream);
  * made inside the library; profiles and the bench's per-kernel table name launches by it.  "" for the paths that do
  * not report (generic kernel, flow heads).  Launches nothing. */
 int fn2_conv2d_kernel_name(const fn2_conv_desc* desc, char* name, int cap);
+/* Number of K splits fn2_conv2d(desc) takes with desc's workspace (1 = no split-K: no slabs, no finalize pass). */
+int fn2_conv2d_splits(const fn2_conv_desc* desc);
 
 /* Flow head (predict_flowN: 3x3, stride 1, pad 1, 2 outputs; flownet_s.py:54-56) as a GEMM: run fn2_conv2d as a
  * 1x1 convolution with 18 outputs t[pix][tap*2+co] (weight w1x1[ci][tap*2+co] = w[ky][kx][ci][co]) into an fp32
@@ -238,6 +250,12 @@ int fn2_flow_head_gather(const float* t, int t_cs, const float* bias, float* out
  * fn2_flow_head_ring and must be taken from there. */
 int fn2_flow_head_tail(const float* t, int t_cs, int taps, const float* bias, float* pf, int n, int h, int w, int ring,
                        const float* up_w, const float* up_bias, const fn2_tensor* up_out, void* stream);
+/* The same with t given as `nslab` raw split-K slabs (fn2_conv_desc.raw_partials): slab s at t + s * slab_stride floats,
+ * [n*h*w][t_cs] each; a partial = scale * (slab 0 + slab 1 + ...), the sum in split order -- bit for bit what the GEMM's
+ * finalize pass would have stored. */
+int fn2_flow_head_tail_slabs(const float* t, int t_cs, int nslab, int64_t slab_stride, float scale, int taps, const float* bias,
+                             float* pf, int n, int h, int w, int ring, const float* up_w, const float* up_bias,
+                             const fn2_tensor* up_out, void* stream);
 /* The interior of a composed head in ONE launch, without the partials ever leaving the chip: for every pixel not on the
  * outermost ring (all pixels when ring == 0)
  *   pf[n,y,x,o] = bias[o] + sum_{u in 5x5} sum_ci w5[u][ci][o] x[n, y+uy-2, x+ux-2, ci]            (x zero outside the image)

@@ -514,6 +514,37 @@ def test_flow_head_tail(taps, N, H, W, up_dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("taps,N,H,W,nslab", [(3, 2, 24, 40, 3), (5, 1, 13, 70, 4), (3, 1, 64, 512, 2)])
+def test_flow_head_tail_sums_raw_split_k_slabs(taps, N, H, W, nslab):
+    """fn2_flow_head_tail_slabs: the partial tensor given as the raw split-K slabs of the GEMM that made it
+    (fn2_conv_desc.raw_partials) -- scale * (slab 0 + slab 1 + ...), summed in split order -- equals, bit for bit, the tail
+    on the tensor a finalize pass would have stored."""
+    from src import _hip
+    lib = _hip.lib()
+    rng = np.random.default_rng(taps * 100 + nslab)
+    cs = 2 * taps * taps + 2          # round_up(Cout, 4): 20 / 52
+    slabs = rng.standard_normal((nslab, N, H, W, cs)).astype(np.float32)
+    scale = np.float32(0.125)
+    summed = slabs[0].copy()
+    for sl in range(1, nslab):
+        summed = summed + slabs[sl]
+    summed = summed * scale
+    bias = torch.tensor([0.5, -0.25], device="cuda")
+    pf_a = torch.zeros((N, H, W, 2), device="cuda")
+    pf_b = torch.zeros_like(pf_a)
+    sd, td = torch.from_numpy(slabs).cuda(), torch.from_numpy(summed).cuda()
+    _hip.check(lib.fn2_flow_head_tail(td.data_ptr(), cs, taps, bias.data_ptr(), pf_a.data_ptr(), N, H, W, 0, None, None, None,
+                                      _hip.stream_ptr()))
+    _hip.check(lib.fn2_flow_head_tail_slabs(sd.data_ptr(), cs, nslab, N * H * W * cs, C.c_float(float(scale)), taps,
+                                            bias.data_ptr(), pf_b.data_ptr(), N, H, W, 0, None, None, None, _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(pf_a, pf_b)
+    with pytest.raises(ValueError):
+        _hip.check(lib.fn2_flow_head_tail_slabs(sd.data_ptr(), cs, nslab, 5, C.c_float(1.0), taps, bias.data_ptr(),
+                                                pf_b.data_ptr(), N, H, W, 0, None, None, None, _hip.stream_ptr()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("kind,k,s,p,cin,cout,N,H,W", [
     ("conv", 5, 2, 2, 64, 128, 2, 48, 64),      # conv2: 5x5 stride 2 (flownet_s.py:40)

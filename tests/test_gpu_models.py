@@ -474,7 +474,8 @@ def test_upsample_flow_riding_on_the_transposed_conv(model, shape, monkeypatch):
     """fn2_conv_desc.up_src: without a head lane the engine lets upsample_flow(N+1)toN (flownet_s.py:60-63) ride on the
     launch of deconvN -- in its split-K finalize pass, or as the stand-alone kernel behind a launch that has none.  Same
     arithmetic, tap for tap: every prediction equals the plan with the upsample as its own launch bit for bit, and the
-    plan is shorter by the launches that rode."""
+    plan is shorter by the launches that rode.  The plain flow heads in front of those transposed convs ride as well
+    (fn2_conv_desc.head: extra blocks of the split-K launch, or fn2_conv2d(head) in front of any other launch)."""
     from src import weights as W
     from src.engine import Engine
     n, h, w = shape
@@ -488,7 +489,8 @@ def test_upsample_flow_riding_on_the_transposed_conv(model, shape, monkeypatch):
     eng = Engine(model, wts, n, h, w, "f16x2")
     got = eng(a, b)
     rode = [d for d in eng.conv_descs if d.up_src]
-    assert rode and len(eng.ops) == len(base.ops) - len(rode)
+    heads = [d for d in eng.conv_descs if d.head]     # plain flow heads taken along by the transposed conv behind them
+    assert rode and heads and len(eng.ops) == len(base.ops) - len(rode) - len(heads)
     assert any(bool(eng.lib.fn2_conv2d_workspace_bytes(d)) for d in rode)   # finalize passes did it
     for k in want:
         assert torch.equal(got[k], want[k]), k
@@ -509,6 +511,35 @@ def test_upsample_flow_riding_on_the_transposed_conv(model, shape, monkeypatch):
     d.workspace, d.workspace_bytes = ws, wsb
     torch.cuda.synchronize()
     assert torch.equal(buf.view(torch.float32)[..., g0:g0 + 8], before.view(torch.float32)[..., g0:g0 + 8])
+    eng.capture()
+    eng(a, b)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(eng.outputs[k], want[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,shape", [("FlowNetS", (2, 256, 384)), ("FlowNetSD", (2, 128, 192))])
+def test_head_gemm_slabs_summed_by_the_tail(model, shape, monkeypatch):
+    """GEMM-form flow heads whose 1x1 GEMM splits K keep the raw slabs (fn2_conv_desc.raw_partials) and the tail launch sums
+    them: the plan loses one finalize launch per such head and every prediction stays bit for bit what the finalize form
+    gives (same additions in the same order)."""
+    from src import weights as W
+    from src.engine import Engine
+    n, h, w = shape
+    wts = W.init_weights(model, 78)
+    a, b = images(n, h, w, 10)
+    monkeypatch.setenv("FN2_HEAD_GEMM_MIN", "2048")   # predict_flow3 of this size as a GEMM too: its K (386 channels) splits
+    monkeypatch.setenv("FN2_HEAD_SLABS", "0")
+    base = Engine(model, wts, n, h, w, "f16x2")
+    want = {k: v.clone() for k, v in base(a, b).items()}
+    monkeypatch.setenv("FN2_HEAD_SLABS", "1")
+    eng = Engine(model, wts, n, h, w, "f16x2")
+    raw = [d for d in eng.conv_descs if d.raw_partials]
+    assert raw and all(eng.lib.fn2_conv2d_splits(d) > 1 for d in raw)
+    got = eng(a, b)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
     eng.capture()
     eng(a, b)
     torch.cuda.synchronize()
