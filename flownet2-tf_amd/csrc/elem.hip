@@ -25,15 +25,41 @@ __device__ __forceinline__ void warp3(const float* __restrict__ img, long nb, in
   o[2] = cTL * tl.b + cTR * tr.b + cBL * bl.b + cBR * br.b;
 }
 
+// A full-resolution flow field given either as itself (ph == 0: `p` is [N,H,W,2]) or as the quarter-resolution
+// predict_flow2 it is resized from (`flow = resize_bilinear(scale * predict_flow2)`, align_corners, flownet_s.py:105-109):
+// then the consumer interpolates its pixel itself -- resize_bilinear_c2_kernel's arithmetic, operation for operation --
+// and, when `keep` is set, stores it there as the resize launch would have.
+struct FlowSrc { const float* p; int ph, pw; float sy, sx, scale; float* keep; };
+
+__device__ __forceinline__ float2 flow_at(const FlowSrc& f, int n, int y, int x, long pix) {
+  if (f.ph == 0) return *reinterpret_cast<const float2*>(f.p + pix * 2);
+  const float fy = (float)y * f.sy;
+  const int y0 = (int)floorf(fy);
+  const int y1 = min(y0 + 1, f.ph - 1);
+  const float ly = fy - (float)y0;
+  const float2* r0 = reinterpret_cast<const float2*>(f.p) + ((long)n * f.ph + y0) * f.pw;
+  const float2* r1 = reinterpret_cast<const float2*>(f.p) + ((long)n * f.ph + y1) * f.pw;
+  const float fx = (float)x * f.sx;
+  const int x0 = (int)floorf(fx);
+  const int x1 = min(x0 + 1, f.pw - 1);
+  const float lx = fx - (float)x0;
+  float2 r = bilerp_c2(r0[x0], r0[x1], r1[x0], r1[x1], lx, ly, f.scale);
+  // the vector is used as the resize launch would have STORED it: without this the final multiply by `scale` contracts
+  // with the consumer's first addition (x + u in the warp) and the results differ in the last bit
+  asm volatile("" : "+v"(r.x), "+v"(r.y));
+  if (f.keep != nullptr) *reinterpret_cast<float2*>(f.keep + pix * 2) = r;
+  return r;
+}
+
 template <typename OutT>
 __global__ void __launch_bounds__(256) stack_input_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          const float* __restrict__ flow, OutT* __restrict__ out,
+                                                          const FlowSrc flow, OutT* __restrict__ out,
                                                           int N, int H, int W, int out_cs, int out_c0, int pad) {
   const long npix = (long)N * H * W;
   for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
     const int x = (int)(pix % W), y = (int)((pix / W) % H);
     const long nb = (pix / W / H) * (long)H * W;
-    const float2 f = *reinterpret_cast<const float2*>(flow + pix * 2);
+    const float2 f = flow_at(flow, (int)(pix / W / H), y, x, pix);
     float wv[3];
     warp3(b, nb, x, y, f.x, f.y, W, H, wv);
     float v[16];
@@ -60,15 +86,14 @@ __global__ void __launch_bounds__(256) stack_input_kernel(const float* __restric
 
 template <typename OutT>
 __global__ void __launch_bounds__(256) fusion_input_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                           const float* __restrict__ fsd,
-                                                           const float* __restrict__ fcss, OutT* __restrict__ out,
+                                                           const FlowSrc fsd, const FlowSrc fcss, OutT* __restrict__ out,
                                                            int N, int H, int W, int out_cs, int out_c0, int pad) {
   const long npix = (long)N * H * W;
   for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
     const int x = (int)(pix % W), y = (int)((pix / W) % H);
     const long nb = (pix / W / H) * (long)H * W;
-    const float2 sd = *reinterpret_cast<const float2*>(fsd + pix * 2);
-    const float2 cs = *reinterpret_cast<const float2*>(fcss + pix * 2);
+    const float2 sd = flow_at(fsd, (int)(pix / W / H), y, x, pix);
+    const float2 cs = flow_at(fcss, (int)(pix / W / H), y, x, pix);
     float wsd[3], wcs[3];
     warp3(b, nb, x, y, sd.x, sd.y, W, H, wsd);  // flownet2.py:33
     warp3(b, nb, x, y, cs.x, cs.y, W, H, wcs);  // flownet2.py:37
@@ -151,25 +176,66 @@ int fn2_u8_to_f32_lut(const unsigned char* src, const float* lut256, float* dst,
   return FN2_OK;
 }
 
+static FlowSrc flow_src(const float* p, int ph, int pw, float scale, float* keep, int out_h, int out_w) {
+  FlowSrc f{p, ph, pw, 0.f, 0.f, scale, keep};
+  if (ph > 0) {   // fn2_resize_bilinear_f32's scales
+    f.sy = out_h > 1 ? (float)(ph - 1) / (float)(out_h - 1) : 0.f;
+    f.sx = out_w > 1 ? (float)(pw - 1) / (float)(out_w - 1) : 0.f;
+  }
+  return f;
+}
+
+static int stack_input_launch(const float* a, const float* b, const FlowSrc& f, const fn2_tensor* out, int pad, void* stream) {
+  const long npix = (long)out->n * (out->h - 2 * pad) * (out->w - 2 * pad);
+  if (out->dtype == FN2_F32)
+    hipLaunchKernelGGL(stack_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, f, (float*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+  else if (out->dtype == FN2_F16X2)
+    hipLaunchKernelGGL(stack_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, f, (x2_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+  else if (out->dtype == FN2_BF16)
+    hipLaunchKernelGGL(stack_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, f, (bf16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+  else
+    hipLaunchKernelGGL(stack_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, f, (f16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+  FN2_CHECK_LAUNCH("stack_input");
+  return FN2_OK;
+}
+
 int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2_tensor* out, int pad, void* stream) {
   FN2_REQUIRE(a && b && flow, "stack_input: null pointer");
   int rc = check_out16(out, 12, "stack_input");
   if (rc) return rc;
   FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "bad border");
+  return stack_input_launch(a, b, flow_src(flow, 0, 0, 1.f, nullptr, 0, 0), out, pad, stream);
+}
+
+int fn2_stack_input_pf(const float* a, const float* b, const float* pf, int pf_h, int pf_w, float scale, float* flow_out,
+                       const fn2_tensor* out, int pad, void* stream) {
+  FN2_REQUIRE(a && b && pf && pf_h >= 1 && pf_w >= 1, "stack_input_pf: null pointer / bad size");
+  int rc = check_out16(out, 12, "stack_input_pf");
+  if (rc) return rc;
+  FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "bad border");
+  return stack_input_launch(a, b, flow_src(pf, pf_h, pf_w, scale, flow_out, out->h - 2 * pad, out->w - 2 * pad), out, pad, stream);
+}
+
+static int fusion_input_launch(const float* a, const float* b, const FlowSrc& fs, const FlowSrc& fc, const fn2_tensor* out,
+                               int pad, void* stream) {
   const long npix = (long)out->n * (out->h - 2 * pad) * (out->w - 2 * pad);
   if (out->dtype == FN2_F32)
-    hipLaunchKernelGGL(stack_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (float*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+    hipLaunchKernelGGL(fusion_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       b, fs, fc, (float*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else if (out->dtype == FN2_F16X2)
-    hipLaunchKernelGGL(stack_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (x2_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+    hipLaunchKernelGGL(fusion_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, fs, fc, (x2_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else if (out->dtype == FN2_BF16)
-    hipLaunchKernelGGL(stack_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (bf16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+    hipLaunchKernelGGL(fusion_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, fs, fc, (bf16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
   else
-    hipLaunchKernelGGL(stack_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow, (f16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
-  FN2_CHECK_LAUNCH("stack_input");
+    hipLaunchKernelGGL(fusion_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, b, fs, fc, (f16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
+  FN2_CHECK_LAUNCH("fusion_input");
   return FN2_OK;
 }
 
@@ -179,21 +245,20 @@ int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const
   int rc = check_out16(out, 11, "fusion_input");
   if (rc) return rc;
   FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "bad border");
-  const long npix = (long)out->n * (out->h - 2 * pad) * (out->w - 2 * pad);
-  if (out->dtype == FN2_F32)
-    hipLaunchKernelGGL(fusion_input_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       b, flow_sd, flow_css, (float*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
-  else if (out->dtype == FN2_F16X2)
-    hipLaunchKernelGGL(fusion_input_kernel<x2_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       a, b, flow_sd, flow_css, (x2_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
-  else if (out->dtype == FN2_BF16)
-    hipLaunchKernelGGL(fusion_input_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       a, b, flow_sd, flow_css, (bf16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
-  else
-    hipLaunchKernelGGL(fusion_input_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream,
-                       a, b, flow_sd, flow_css, (f16_t*)out->data, out->n, out->h - 2 * pad, out->w - 2 * pad, out->cs, out->c0, pad);
-  FN2_CHECK_LAUNCH("fusion_input");
-  return FN2_OK;
+  return fusion_input_launch(a, b, flow_src(flow_sd, 0, 0, 1.f, nullptr, 0, 0), flow_src(flow_css, 0, 0, 1.f, nullptr, 0, 0),
+                             out, pad, stream);
+}
+
+int fn2_fusion_input_pf(const float* a, const float* b, const float* pf_sd, float scale_sd, float* flow_sd_out,
+                        const float* pf_css, float scale_css, float* flow_css_out, int pf_h, int pf_w,
+                        const fn2_tensor* out, int pad, void* stream) {
+  FN2_REQUIRE(a && b && pf_sd && pf_css && pf_h >= 1 && pf_w >= 1, "fusion_input_pf: null pointer / bad size");
+  int rc = check_out16(out, 11, "fusion_input_pf");
+  if (rc) return rc;
+  FN2_REQUIRE(pad >= 0 && out->h > 2 * pad && out->w > 2 * pad, "bad border");
+  const int oh = out->h - 2 * pad, ow = out->w - 2 * pad;
+  return fusion_input_launch(a, b, flow_src(pf_sd, pf_h, pf_w, scale_sd, flow_sd_out, oh, ow),
+                             flow_src(pf_css, pf_h, pf_w, scale_css, flow_css_out, oh, ow), out, pad, stream);
 }
 
 }  // extern "C"

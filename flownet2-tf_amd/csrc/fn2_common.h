@@ -80,6 +80,17 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
   hi = __builtin_bit_cast(uint4, h);
   lo = __builtin_bit_cast(uint4, l);
 }
+// One two-channel pixel of tf.image.resize_bilinear(align_corners=True) times `scale` from its four neighbours.  Shared by
+// the resize kernel (ops.hip) and the ops that interpolate their own flow vector (elem.hip: flow_at), so that
+// both produce the same bits whatever the surrounding code is.
+__device__ __forceinline__ float2 bilerp_c2(const float2 tl, const float2 tr, const float2 bl, const float2 br, float lx,
+                                            float ly, float scale) {
+  // every multiply-add is an EXPLICIT fma: nothing is left for the compiler to contract one way here and another way there
+  const float top0 = __builtin_fmaf(tr.x - tl.x, lx, tl.x), bot0 = __builtin_fmaf(br.x - bl.x, lx, bl.x);
+  const float top1 = __builtin_fmaf(tr.y - tl.y, lx, tl.y), bot1 = __builtin_fmaf(br.y - bl.y, lx, bl.y);
+  return make_float2(__builtin_fmaf(bot0 - top0, ly, top0) * scale, __builtin_fmaf(bot1 - top1, ly, top1) * scale);
+}
+
 __device__ __forceinline__ void join8(const uint4& hi, const uint4& lo, float* v) {
   typedef __attribute__((ext_vector_type(8))) _Float16 h8;
   const h8 h = __builtin_bit_cast(h8, hi), l = __builtin_bit_cast(h8, lo);

@@ -563,11 +563,9 @@ __global__ void __launch_bounds__(256) resize_bilinear_c2_kernel(const float* __
     const int x0 = (int)floorf(fx);
     const int x1 = min(x0 + 1, Win - 1);
     const float lx = fx - (float)x0;
-    const float2 tl = r0[x0], tr = r0[x1], bl = r1[x0], br = r1[x1];
-    const float top0 = tl.x + (tr.x - tl.x) * lx, bot0 = bl.x + (br.x - bl.x) * lx;
-    const float top1 = tl.y + (tr.y - tl.y) * lx, bot1 = bl.y + (br.y - bl.y) * lx;
-    res[2 * j] = (top0 + (bot0 - top0) * ly) * scale;
-    res[2 * j + 1] = (top1 + (bot1 - top1) * ly) * scale;
+    const float2 r = bilerp_c2(r0[x0], r0[x1], r1[x0], r1[x1], lx, ly, scale);
+    res[2 * j] = r.x;
+    res[2 * j + 1] = r.y;
   }
   *reinterpret_cast<float4*>(out + ((long)blockIdx.y * ow + 2 * xp) * 2) = make_float4(res[0], res[1], res[2], res[3]);
 }

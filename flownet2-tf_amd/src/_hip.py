@@ -87,6 +87,8 @@ PROTOTYPES = {
     "fn2_correlation_fused": (_i, [_tp, _tp, _tp, _i, _i, _i, _p]),
     "fn2_stack_input": (_i, [_p, _p, _p, _tp, _i, _p]),
     "fn2_fusion_input": (_i, [_p, _p, _p, _p, _tp, _i, _p]),
+    "fn2_stack_input_pf": (_i, [_p, _p, _p, _i, _i, _f, _p, _tp, _i, _p]),
+    "fn2_fusion_input_pf": (_i, [_p, _p, _p, _f, _p, _p, _f, _p, _i, _i, _tp, _i, _p]),
     "fn2_epe_loss_grad": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "fn2_epe_loss_grad_weighted": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "fn2_leaky_bwd": (_i, [_tp, _tp, _p, _p]),

@@ -174,6 +174,7 @@ class Engine:
         # head (_composed_head).  Inference engines only (the trainer needs both variables); FN2_COMPOSE=0: off (A/B).
         self.compose_heads = bool(heads_as_gemm) and dtype == "f16x2" and bool(int(os.environ.get("FN2_COMPOSE", "1")))
         self._head_t = None
+        self._defer_flow = False    # building a sub-network of a stack whose flow is resized by its consumer (_final_flow)
         self._own_ws = set()        # descriptors that keep a split-K workspace of their own (_head_slabs)
         self._pending_head = None   # a plain flow head waiting for the transposed conv that takes it along (_conv: defer_head)
         self.outputs = self._build()
@@ -755,8 +756,15 @@ class Engine:
         return preds
 
     def _final_flow(self, tag, preds, scale):
-        """flow = resize_bilinear(scale * predict_flow2) on the head lane; the main lane then waits for it."""
+        """flow = resize_bilinear(scale * predict_flow2) on the head lane; the main lane then waits for it.  Inside a stack
+        (self._defer_flow) the resize is left to the op that consumes the flow -- fn2_stack_input_pf / fn2_fusion_input_pf
+        interpolate per pixel and write the flow buffer too -- so the chain is one launch shorter per sub-network."""
         M, Hd = self._branch, self._head_lane()
+        if self._defer_flow:
+            preds["flow"] = self._buf(f"{tag}/flow", self.N, self.H, self.W, 2, torch.float32)
+            preds["_flow_src"] = (preds["predict_flow2"], scale)
+            self._sync(M, Hd)   # predict_flow2 came from the head lane: its consumer runs on the main lane
+            return preds
         with self._lane(Hd):
             preds["flow"] = self._resize(f"{tag}/flow", preds["predict_flow2"], scale)
         self._sync(M, Hd)
@@ -891,27 +899,41 @@ class Engine:
         self._op(f"{tag}/pack_pair", self.lib.fn2_pack_pair, _hip.ptr(self.in_a), _hip.ptr(self.in_b), C.byref(v), pad)
         return x
 
-    def _stacked_input(self, tag, flow):
+    def _stacked_input(self, tag, preds):
         x = self._buf(f"{tag}/stack", self.N, self.H + 6, self.W + 6, 16, stem=True)
         v = self._v(x, 12, 0)
         self.keep.append(v)
-        self._op(f"{tag}/stack_input", self.lib.fn2_stack_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
-                 _hip.ptr(flow), C.byref(v), 3)  # flow_warp + brightness error + concat, flownet_cs.py:21-36
+        # flow_warp + brightness error + concat, flownet_cs.py:21-36
+        if "_flow_src" in preds:
+            pf2, scale = preds["_flow_src"]
+            self._op(f"{tag}/stack_input", self.lib.fn2_stack_input_pf, _hip.ptr(self.in_a), _hip.ptr(self.in_b), _hip.ptr(pf2),
+                     pf2.shape[1], pf2.shape[2], C.c_float(scale), _hip.ptr(preds["flow"]), C.byref(v), 3, kernel="stack_input")
+        else:
+            self._op(f"{tag}/stack_input", self.lib.fn2_stack_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
+                     _hip.ptr(preds["flow"]), C.byref(v), 3)
         return x
 
+    def _sub(self, build, *args):
+        """A sub-network whose flow goes to a stack_input / fusion_input of the stack (see _final_flow)."""
+        prev, self._defer_flow = self._defer_flow, bool(int(os.environ.get("FN2_FLOW_IN_CONSUMER", "1")))
+        try:
+            return build(*args)
+        finally:
+            self._defer_flow = prev
+
     def _net_cs(self, scope, tag):
-        pc = self._net_c(scope + "/FlowNetC", tag + "/C")
-        return self._net_s(scope + "/FlowNetS", tag + "/S", self._stacked_input(tag + "/S", pc["flow"]), 12)
+        pc = self._sub(self._net_c, scope + "/FlowNetC", tag + "/C")
+        return self._net_s(scope + "/FlowNetS", tag + "/S", self._stacked_input(tag + "/S", pc), 12)
 
     def _net_css(self, scope, tag):
-        pcs = self._net_cs(scope + "/FlowNetCS", tag + "/CS")
-        return self._net_s(scope + "/FlowNetS", tag + "/S", self._stacked_input(tag + "/S", pcs["flow"]), 12)
+        pcs = self._sub(self._net_cs, scope + "/FlowNetCS", tag + "/CS")
+        return self._net_s(scope + "/FlowNetS", tag + "/S", self._stacked_input(tag + "/S", pcs), 12)
 
     def _net_2(self, scope, tag):
         """FlowNet2.model (flownet2.py:18-105)."""
         N, H, W_ = self.N, self.H, self.W
         fork = len(self.ops)  # FlowNetSD (lane 1) depends on nothing but the images: it forks here, in front of the chain
-        css = self._net_css(scope + "/FlowNetCSS", tag + "/CSS")
+        css = self._sub(self._net_css, scope + "/FlowNetCSS", tag + "/CSS")
         if self._lanes_on and self._lane_mask & 2:
             self.syncs.append((fork, 1, 0))
             if self._lane_mask & 8 and int(os.environ.get("FN2_FORK3", "1")):
@@ -919,15 +941,21 @@ class Engine:
                 # capture by waiting on ANOTHER forked stream crashed hipStreamEndCapture / hipGraphInstantiate (ROCm 7.2)
                 self.syncs.append((fork, 3, 0))
         with self._lane(1):
-            sd = self._net_sd(scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD", 1))
+            sd = self._sub(self._net_sd, scope + "/FlowNetSD", tag + "/SD", self._pair_input(tag + "/SD", 1))
         if self._lanes_on and self._lane_mask & 2:
             self._sync(0, 1)
         L = {s[0]: s for s in netdefs.fusion_layers()}
         xf = self._buf(f"{tag}/fusion_in", N, H + 2, W_ + 2, 16, stem=True)
         v = self._v(xf, 11, 0)
         self.keep.append(v)
-        self._op(f"{tag}/fusion_input", self.lib.fn2_fusion_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
-                 _hip.ptr(sd["flow"]), _hip.ptr(css["flow"]), C.byref(v), 1)
+        if "_flow_src" in sd and "_flow_src" in css:
+            (pf_sd, s_sd), (pf_css, s_css) = sd["_flow_src"], css["_flow_src"]
+            self._op(f"{tag}/fusion_input", self.lib.fn2_fusion_input_pf, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
+                     _hip.ptr(pf_sd), C.c_float(s_sd), _hip.ptr(sd["flow"]), _hip.ptr(pf_css), C.c_float(s_css),
+                     _hip.ptr(css["flow"]), pf_sd.shape[1], pf_sd.shape[2], C.byref(v), 1, kernel="fusion_input")
+        else:
+            self._op(f"{tag}/fusion_input", self.lib.fn2_fusion_input, _hip.ptr(self.in_a), _hip.ptr(self.in_b),
+                     _hip.ptr(sd["flow"]), _hip.ptr(css["flow"]), C.byref(v), 1)
         cat0 = self._buf(f"{tag}/concat0", N, H, W_, 82)
         cat1 = self._buf(f"{tag}/concat1", N, H // 2, W_ // 2, 162)
         self._conv_stem(scope, L["fuse_conv0"], xf, (cat0, 0, 64))

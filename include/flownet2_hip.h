@@ -321,6 +321,16 @@ int fn2_stack_input(const float* a, const float* b, const float* flow, const fn2
  * [a(3) | flow_sd(2) | flow_css(2) | |sd| | |css| | |a-warp(b,sd)| | |a-warp(b,css)| | 0...]. */
 int fn2_fusion_input(const float* a, const float* b, const float* flow_sd, const float* flow_css,
                      const fn2_tensor* out, int pad, void* stream);
+/* The same two ops fed with the quarter-resolution predict_flow2 tensors ([n, pf_h, pf_w, 2] fp32) the flows are resized
+ * from -- flow = resize_bilinear(scale * predict_flow2) (align_corners; flownet_s.py:105-109, flownet_c.py:113-118,
+ * flownet_sd.py:104-108): every pixel interpolates its own flow vector with fn2_resize_bilinear_f32's arithmetic, so the
+ * resize launch in front of the op disappears from a stack's chain; flow_out (NULL: skip) receives the full-resolution
+ * flow as that launch would have written it.  Bit-identical to resize + op. */
+int fn2_stack_input_pf(const float* a, const float* b, const float* pf, int pf_h, int pf_w, float scale, float* flow_out,
+                       const fn2_tensor* out, int pad, void* stream);
+int fn2_fusion_input_pf(const float* a, const float* b, const float* pf_sd, float scale_sd, float* flow_sd_out,
+                        const float* pf_css, float scale_css, float* flow_css_out, int pf_h, int pf_w,
+                        const fn2_tensor* out, int pad, void* stream);
 
 /* ---------------------------------------------------------------- training step (fp32)
  * What the reference obtains from tf.gradients + tf.train.AdamOptimizer over the FlowNetS loss

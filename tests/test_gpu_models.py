@@ -545,3 +545,31 @@ def test_head_gemm_slabs_summed_by_the_tail(model, shape, monkeypatch):
     torch.cuda.synchronize()
     for k in want:
         assert torch.equal(eng.outputs[k], want[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,shape", [("FlowNetCSS", (2, 128, 192)), ("FlowNet2", (1, 128, 256))])
+def test_flow_resize_inside_the_consuming_op(model, shape, monkeypatch):
+    """Inside a stack the flow of a sub-network -- resize_bilinear(scale * predict_flow2), flownet_s.py:105-109 -- is
+    interpolated per pixel by the op that consumes it (fn2_stack_input_pf: warp + brightness error + concat,
+    flownet_cs.py:21-36; fn2_fusion_input_pf: flownet2.py:25-47), which also writes the flow buffer: one launch less per
+    sub-network on the chain, every tensor bit for bit what resize + op give."""
+    from src import weights as W
+    from src.engine import Engine
+    n, h, w = shape
+    wts = W.init_weights(model, 79)
+    a, b = images(n, h, w, 11)
+    monkeypatch.setenv("FN2_FLOW_IN_CONSUMER", "0")
+    base = Engine(model, wts, n, h, w, "f16x2")
+    want = {k: v.clone() for k, v in base(a, b).items()}
+    monkeypatch.setenv("FN2_FLOW_IN_CONSUMER", "1")
+    eng = Engine(model, wts, n, h, w, "f16x2")
+    got = eng(a, b)
+    nsub = 2 if model == "FlowNetCSS" else 4
+    assert len(eng.ops) == len(base.ops) - nsub
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    flows = [k for k in base.bufs if k.endswith("/flow")]
+    assert len(flows) >= nsub
+    for k in flows:     # the sub-networks' full-resolution flows are still there, written by their consumers
+        assert torch.equal(eng.bufs[k], base.bufs[k]), k
