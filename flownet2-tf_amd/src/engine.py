@@ -935,6 +935,8 @@ class Engine:
         fork = len(self.ops)  # FlowNetSD (lane 1) depends on nothing but the images: it forks here, in front of the chain
         css = self._sub(self._net_css, scope + "/FlowNetCSS", tag + "/CSS")
         if self._lanes_on and self._lane_mask & 2:
+            # FN2_SD_FORK_OPS = launches of the chain FlowNetSD waits for before it starts (0: it forks in front of the chain)
+            fork += min(int(os.environ.get("FN2_SD_FORK_OPS", "0")), len(self.ops) - fork)
             self.syncs.append((fork, 1, 0))
             if self._lane_mask & 8 and int(os.environ.get("FN2_FORK3", "1")):
                 # the SD head lane forks from the capture's origin stream as well: a stream that first enters the
