@@ -812,6 +812,13 @@ class Engine:
         N, H, W_ = self.N, self.H, self.W
         L = {s[0]: s for s in netdefs.flownet_c_layers()}
         cats = self._alloc_cats(tag, N)
+        # FN2_C_TOWERS=batch: conv2 / conv3 of BOTH towers as one launch each over 2N images (the level-2 concat buffer gets N
+        # more images whose first 128 channels hold tower b's conv2) instead of tower b on a lane of its own
+        batch_towers = os.environ.get("FN2_C_TOWERS", "lane") == "batch"
+        if batch_towers:
+            del self.bufs[f"{tag}/concat2"]
+            cat2_all = self._buf(f"{tag}/concat2", 2 * N, H // 4, W_ // 4, 194)
+            cats[2] = cat2_all[:N]
         # both towers' images as 2x2 space-to-depth super-pixels with pad(.., 3) baked in (:30-34): the 7x7
         # stride-2 conv1 then runs as a 4x4 stride-1 row-run convolution over 16-channel super-pixels
         c1 = self._buf(f"{tag}/conv1", 2 * N, H // 2, W_ // 2, 64)
@@ -829,19 +836,25 @@ class Engine:
             self._op(f"{tag}/pack_a", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_a), N, H, W_, C.byref(v), 0, 3)
             self._op(f"{tag}/pack_b", self.lib.fn2_pack_image_s2d, _hip.ptr(self.in_b), N, H, W_, C.byref(v), N, 3)
             self._conv_stem(scope, L["conv1"], x2, (c1, 0, 64), s2d=True)
-        c2b = self._buf(f"{tag}/conv_b_2", N, H // 4, W_ // 4, 128)
-        M, T = self._branch, (4 if (self._lanes_on and self._lane_mask & 16) else self._branch)  # second tower (and conv_redir) on lane 4
-        self._sync(T, M)
-        self._conv(scope, L["conv2"], (c1[:N], 0, 64), (cats[2], 0, 128))  # conv_a_2 = the level-2 skip, :105
-        with self._lane(T):
-            self._conv(scope, L["conv2"], (c1[N:], 0, 64), (c2b, 0, 128))
-        c3a = self._buf(f"{tag}/conv_a_3", N, H // 8, W_ // 8, 256)
-        c3b = self._buf(f"{tag}/conv_b_3", N, H // 8, W_ // 8, 256)
-        self._conv(scope, L["conv3"], (cats[2], 0, 128), (c3a, 0, 256))
-        with self._lane(T):
-            self._conv(scope, L["conv3"], (c2b, 0, 128), (c3b, 0, 256))
-        self._sync(M, T)  # the correlation reads both towers
-        self._sync(T, M)  # conv_redir (lane T, beside the correlation) reads conv_a_3
+        M, T = self._branch, (4 if (self._lanes_on and self._lane_mask & 16 and not batch_towers) else self._branch)  # second tower (and conv_redir) on lane 4
+        if batch_towers:
+            self._conv(scope, L["conv2"], (c1, 0, 64), (cat2_all, 0, 128))  # images [0, N): conv_a_2 = the level-2 skip, :105
+            c3 = self._buf(f"{tag}/conv_ab_3", 2 * N, H // 8, W_ // 8, 256)
+            self._conv(scope, L["conv3"], (cat2_all, 0, 128), (c3, 0, 256))
+            c3a, c3b = c3[:N], c3[N:]
+        else:
+            c2b = self._buf(f"{tag}/conv_b_2", N, H // 4, W_ // 4, 128)
+            self._sync(T, M)
+            self._conv(scope, L["conv2"], (c1[:N], 0, 64), (cats[2], 0, 128))  # conv_a_2 = the level-2 skip, :105
+            with self._lane(T):
+                self._conv(scope, L["conv2"], (c1[N:], 0, 64), (c2b, 0, 128))
+            c3a = self._buf(f"{tag}/conv_a_3", N, H // 8, W_ // 8, 256)
+            c3b = self._buf(f"{tag}/conv_b_3", N, H // 8, W_ // 8, 256)
+            self._conv(scope, L["conv3"], (cats[2], 0, 128), (c3a, 0, 256))
+            with self._lane(T):
+                self._conv(scope, L["conv3"], (c2b, 0, 128), (c3b, 0, 256))
+            self._sync(M, T)  # the correlation reads both towers
+            self._sync(T, M)  # conv_redir (lane T, beside the correlation) reads conv_a_3
         net = self._buf(f"{tag}/corr_concat", N, H // 8, W_ // 8, 473)  # [conv_redir(32) | corr(441)], :46
         va, vb, vo = self._v(c3a, 256, 0), self._v(c3b, 256, 0), self._v(net, 441, 32)
         self.keep += [va, vb, vo]
