@@ -956,9 +956,9 @@ static int build_args(const fn2_conv_desc* d, ConvArgs* out, int* tile_out, int*
               "conv2d: kind must be 0 (conv), 1 (deconv k4 s2 crop 1), 2 (stem row-run conv), 3 (transpose of a stride-2 conv) "
               "or 5 (deconv k4 s2 crop 1, column phases merged)");
   FN2_REQUIRE(d->in.n == d->out.n, "conv2d: batch mismatch");
-  FN2_REQUIRE(d->up_src == nullptr || (d->kind == 1 && d->up_w != nullptr && d->up_c0 >= 0 && d->up_c0 + 2 <= d->out.cs &&
-                                       !d->accumulate),
-              "conv2d: up_src rides on a kind-1 transposed conv (up_w set, [up_c0, up_c0 + 2) inside the out buffer)");
+  FN2_REQUIRE(d->up_src == nullptr || ((d->kind == 1 || d->kind == 5) && d->up_w != nullptr && d->up_c0 >= 0 &&
+                                       d->up_c0 + 2 <= d->out.cs && !d->accumulate),
+              "conv2d: up_src rides on a kind-1 / kind-5 transposed conv (up_w set, [up_c0, up_c0 + 2) inside the out buffer)");
   FN2_REQUIRE(d->cin_pad % 8 == 0 && d->cin_pad >= d->in.c, "conv2d: cin_pad must be a multiple of 8 >= Cin");
   FN2_REQUIRE(d->in.cs % 8 == 0 && d->in.c0 % 8 == 0, "conv2d: input channel stride/offset must be multiples of 8");
   if (d->kind != 2)
@@ -1296,6 +1296,9 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
     a.splitk = sk;
     a.ws = reinterpret_cast<float*>(d->workspace);
   }
+  if (d->up_src != nullptr && d->kind == 5 && 2 * d->out.c == 32) {   // one lane per output pixel holds all its channels
+    a.up_src = d->up_src; a.up_w = d->up_w; a.up_bias = d->up_bias; a.up_c0 = d->up_c0;
+  }
   if (d->head != nullptr && !conv_name_sink().buf) {
     // fn2_conv_desc.head: ride on this launch when it is the split-K split-fp16 launch on fragment-order weights (conv2.hip:
     // the head pixels are extra z slices of its grid), else run in front of it
@@ -1340,7 +1343,7 @@ int fn2_conv2d(const fn2_conv_desc* d, void* stream) {
   else rc = launch_conv<f16_t, float>(a, tile, phases, s);
   if (rc || conv_name_sink().buf) return rc;
   if (a.splitk == 1) {
-    if (d->up_src == nullptr) return rc;
+    if (d->up_src == nullptr || a.up_src != nullptr) return rc;   // (a.up_src: the kind-5 epilogue did it)
     // no finalize pass to ride on: the stand-alone upsample_flow kernel behind the convolution
     fn2_tensor uv = d->out;
     uv.c = 2; uv.c0 = d->up_c0;

@@ -1100,6 +1100,30 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvArgs p) {
         for (int q = 0; q < 16; ++q)
           if (cout_base + q < p.Cout) store_elem<OutT>(po + q, v[q]);
       }
+      if (p.merged && p.up_src != nullptr && cout_base == 0 && ox < p.OW) {
+        // upsample_flowXtoY of this output pixel (upsample_flow_kernel's arithmetic, tap for tap; conv.hip)
+        const int uy = toy * osc + oy_off, ux = ox * osc + ox_off + bsel;
+        const int H2 = p.out_H >> 1, W2 = p.out_W >> 1;
+        const int a = uy & 1, b = ux & 1, y = uy >> 1, x = ux >> 1;
+        float r0 = p.up_bias ? p.up_bias[0] : 0.f, r1 = p.up_bias ? p.up_bias[1] : 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+          const int iy = y - 1 + a + ty, ky = 3 - a - 2 * ty;
+          if (iy < 0 || iy >= H2) continue;
+#pragma unroll
+          for (int tx = 0; tx < 2; ++tx) {
+            const int ix = x - 1 + b + tx, kx = 3 - b - 2 * tx;
+            if (ix < 0 || ix >= W2) continue;
+            const float2 sv = *reinterpret_cast<const float2*>(p.up_src + (((long)tn * H2 + iy) * W2 + ix) * 2);
+            const float* ww = p.up_w + (ky * 4 + kx) * 4;
+            r0 += sv.x * ww[0] + sv.y * ww[1];
+            r1 += sv.x * ww[2] + sv.y * ww[3];
+          }
+        }
+        OutT* pu = out + (((size_t)tn * p.out_H + uy) * p.out_W + ux) * p.out_cs + p.up_c0;
+        store_elem<OutT>(pu, r0);
+        store_elem<OutT>(pu + 1, r1);
+      }
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -41,6 +41,9 @@ struct ConvArgs {
   float* fh_out;              // fp32 view [n, h, w, fh_out_cs] + fh_out_c0
   int fh_out_cs, fh_out_c0;
   float fh_scale;
+  // fn2_conv_desc.up_src on a kind-5 launch (conv_halo_kernel, merged column phases): the lane that holds an output pixel's
+  // Cout channels also writes upsample_flow(N+1)toN of that pixel to channels [up_c0, up_c0 + 2) of the out buffer
+  const float* up_src; const float* up_w; const float* up_bias; int up_c0;
   int wfrag;    // 1: the weight is stored in MFMA-fragment order (wgt_layout 2) and loaded straight into registers (conv2.hip, WREG)
   int accum;    // 1: out += result (fp32 outputs; gradient accumulation into shared buffers)
   int vec_ok;  // out_cs % 4 == 0 && out_c0 % 4 == 0

@@ -363,7 +363,7 @@ class Engine:
             d.head = C.addressof(hd)
             self._pending_head = None
         if up_after is not None:
-            assert kind != "conv" and not merged
+            assert kind != "conv" and (not merged or cout == 16)   # (kind 5 with 16 outputs: its epilogue writes the two channels)
             up_name, up_src, (ubuf, uc0, uc) = up_after
             assert ubuf is dbuf and uc == 2
             uw = W.to_device(self._w(f"{scope}/{up_name}/weights"), torch.float32, self.device)
@@ -1007,8 +1007,12 @@ class Engine:
             with self._lane(Hd):
                 fused = self._conv(scope, L["predict_flow1"], (ic1, 0, 32), (pf1, 0, 2),
                                    up=("fuse_upsample_flow1to0", (cat0, 80, 2)))
-        self._conv(scope, L["fuse_deconv0"], (cat1, 0, 162), (cat0, 64, 16))
-        if not fused:
+        # (no head lane: fuse_upsample_flow1to0 rides on fuse_deconv0 -- the merged-phase epilogue, or a finalize pass)
+        ride0 = (not fused and Hd == M and self.dtype_name == "f16x2" and self.heads_as_gemm
+                 and bool(int(os.environ.get("FN2_UP_IN_DECONV", "1"))))
+        self._conv(scope, L["fuse_deconv0"], (cat1, 0, 162), (cat0, 64, 16),
+                   up_after=("fuse_upsample_flow1to0", pf1, (cat0, 80, 2)) if ride0 else None)
+        if not fused and not ride0:
             with self._lane(Hd):
                 self._upflow(scope, "fuse_upsample_flow1to0", pf1, (cat0, 80, 2))
         self._sync(M, Hd)

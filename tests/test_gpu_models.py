@@ -469,13 +469,15 @@ def test_model_runs_a_batch_above_the_tensor_limit_in_chunks(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model,shape", [("FlowNetS", (2, 128, 192)), ("FlowNetSD", (1, 64, 128)), ("FlowNetS", (6, 256, 384))])
+@pytest.mark.parametrize("model,shape", [("FlowNetS", (2, 128, 192)), ("FlowNetSD", (1, 64, 128)), ("FlowNetS", (6, 256, 384)),
+                                         ("FlowNet2", (1, 128, 256))])
 def test_upsample_flow_riding_on_the_transposed_conv(model, shape, monkeypatch):
     """fn2_conv_desc.up_src: without a head lane the engine lets upsample_flow(N+1)toN (flownet_s.py:60-63) ride on the
     launch of deconvN -- in its split-K finalize pass, or as the stand-alone kernel behind a launch that has none.  Same
     arithmetic, tap for tap: every prediction equals the plan with the upsample as its own launch bit for bit, and the
     plan is shorter by the launches that rode.  The plain flow heads in front of those transposed convs ride as well
-    (fn2_conv_desc.head: extra blocks of the split-K launch, or fn2_conv2d(head) in front of any other launch)."""
+    (fn2_conv_desc.head: extra blocks of the split-K launch, or fn2_conv2d(head) in front of any other launch).  FlowNet2:
+    the fusion net's fuse_upsample_flow1to0 rides in the epilogue of the merged-phase fuse_deconv0 (kind 5)."""
     from src import weights as W
     from src.engine import Engine
     n, h, w = shape
