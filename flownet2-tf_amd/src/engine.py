@@ -720,8 +720,8 @@ class Engine:
             h, w = cat.shape[1], cat.shape[2]
             # without a head lane the upsample_flow of the level rides on the transposed conv's launch (its split-K
             # finalize pass): one launch less per level on the chain.  FN2_UP_IN_DECONV=0: its own launch (A/B)
-            ride = (not fused and Hd == M and self.heads_as_gemm and self._code(cat) == self.act_code
-                    and bool(int(os.environ.get("FN2_UP_IN_DECONV", "1"))))
+            ride = (not fused and Hd == M and self._code(cat) == self.act_code
+                    and bool(int(os.environ.get("FN2_UP_IN_DECONV", "1"))))   # (the trainer's forward plan as well)
             self._conv(scope, L[f"deconv{lvl}"], (cur, 0, cur_c), (cat, skip_c, dec_c),
                        up_after=(f"upsample_flow{lvl + 1}to{lvl}", pf, (cat, skip_c + dec_c, 2)) if ride else None)
             if not fused and not ride:
