@@ -128,7 +128,11 @@ class Engine:
         # fine-grained fork/joins eat what two long independent chains gain), and lane 3 (cross-waits between two
         # forked streams, neither of them the capture's origin) crashes hipStreamEndCapture on ROCm 7.2.  FlowNetC b8
         # alone: 1.641 -> 1.597 with lanes 2 + 4.
-        default_mask = 0b10011 if model == "FlowNet2" else 0b10101
+        # Round 3: without a head lane the heads and upsample_flows of a decoder level ride on the transposed conv's launch
+        # (_refine), which beats the lane wherever the heads are the plain / GEMM forms: FlowNetS b8 1.099 -> 1.073 ms, b1
+        # 0.405 -> 0.362; FlowNetC b8 1.515 -> 1.500, b1 0.525 -> 0.504 (tower lane kept).  FlowNetSD's composed heads
+        # (ring + GEMM + tail per level) still want their lane: b4 1.019 with, 1.055 without.
+        default_mask = 0b10011 if model == "FlowNet2" else (0b10101 if model == "FlowNetSD" else 0b10001)
         self._lane_mask = int(os.environ.get("FN2_LANE_MASK", str(default_mask)))
         self.keep = []     # keep ctypes structs / tensors alive
         self.bufs = {}
