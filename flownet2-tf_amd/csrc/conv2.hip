@@ -183,8 +183,8 @@ __device__ __forceinline__ float* h5_t(uint4* a, uint4* b, int half, int w) {
 // SLAB (WREG instantiations only) = the launch is a K split: the epilogue is the partial-sum slab store and nothing else
 // (without it a WREG instantiation has no slab code at all); the other instantiations decide at run time.
 template <typename T, typename OutT, int WC, int WP, int TCN = 2, int TPN = 2, int STAGES = 2, int KG = 1, bool M16 = false,
-          bool WREG = false, bool SLAB = false, bool HEAD5 = false>
-__global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p) {
+          bool WREG = false, bool SLAB = false, bool HEAD5 = false, bool FEED = false>
+__global__ void __launch_bounds__(256 * KG + (FEED ? 256 : 0)) conv_igemm2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-descriptor type only exists in the device pass; the host pass needs just the stub
   constexpr int CH = 16 / (int)sizeof(T);
   constexpr int ESZ = (int)sizeof(T);
@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     if (p.fh_M > 0 && (int)blockIdx.z >= p.fh_z0) {
       // predict_flow(N+1) riding on deconvN (fn2_conv_desc.head): the z slices behind the convolution's own are head
       // blocks, a pixel at a time each (they are dispatched last and fill the slots the convolution leaves free)
+      if (FEED && threadIdx.x >= 256) return;   // (fh_pixel is written for 256 threads; ended waves do not count at its barriers)
       float* part = reinterpret_cast<float*>(lds0_all);
       const long e = (((long)blockIdx.z - p.fh_z0) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       const long total = (long)(gridDim.z - p.fh_z0) * gridDim.y * gridDim.x;
@@ -235,7 +236,12 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = KG > 1 ? wave_all >> 2 : 0;   // K group of this wave
-  const int wave = KG > 1 ? wave_all & 3 : wave_all;
+  // FEED (experiment, WREG ring only): waves 4 .. 7 issue the pixel DMA pieces of wave (w - 4)'s rows and nothing else; waves
+  // 0 .. 3 load their weight fragments and multiply (the ~150 cycles a wave spends per LDS-DMA piece then run beside the
+  // MFMAs on the SIMD's other wave slot, as in head5_strip_kernel)
+  static_assert(!FEED || (WREG && STAGES == 3 && KG == 1), "FEED: the WREG ring");
+  const bool feeder = FEED && wave_all >= 4;
+  const int wave = (KG > 1 || FEED) ? wave_all & 3 : wave_all;
   uint4* const lds0 = lds0_all + grp * (ROWS * 8);
   uint4* const lds1 = WREG ? lds0_all + BP * 8 : kDeep ? lds0_all + ROWS * 8 : lds1_all + grp * (ROWS * 8);
   uint4* const lds2 = WREG ? lds0_all + 2 * BP * 8 : lds2_own;
@@ -553,7 +559,40 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   // Two stages per trip so that every LDS access names its object statically (see the lds0/lds1 note), and no
   // branch between them: an odd stage count is rounded up with a stage whose pixel rows are all zero (the
   // validity test in issue_piece fails for stages >= kt1), so its MFMAs add 0 * stale finite weights.
-  if constexpr (WREG && STAGES == 3) {
+  if constexpr (FEED) {
+    const int nst3 = (kt1 - kt0 + 2) / 3 * 3;
+    auto pix_stage = [&](uint4* lds) {   // this feeder's pixel pieces of the next stage
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        (issue_piece(std::integral_constant<int, NWI + I>{}, lds), ...);
+      }(std::make_integer_sequence<int, NPI>{});
+      advance();
+    };
+    if (feeder) {
+      static_assert(NPI == 2, "vmcnt literal below");
+      pix_stage(lds0);
+      pix_stage(lds1);
+      for (int s = 0; s < nst3; s += 3) {
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); pix_stage(lds2);
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); pix_stage(lds0);
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); pix_stage(lds1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      auto w_stage = [&](u32x4_t (&wf)[4]) { load_w(wf); advance(); };
+      auto sync_c = [&](u32x4_t (&wf)[4]) {   // this wave's fragments of the stage have landed (the next stage's four loads may be in flight)
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) :: "memory");
+      };
+      w_stage(wfa);
+      w_stage(wfb);
+      for (int s = 0; s < nst3; s += 3) {
+        sync_c(wfa); w_stage(wfc); compute_w(lds0, wfa);
+        sync_c(wfb); w_stage(wfa); compute_w(lds1, wfb);
+        sync_c(wfc); w_stage(wfb); compute_w(lds2, wfc);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(wfa[0]), "+v"(wfa[1]), "+v"(wfa[2]), "+v"(wfa[3]), "+v"(wfb[0]), "+v"(wfb[1]),
+                   "+v"(wfb[2]), "+v"(wfb[3]) :: "memory");
+    }
+  } else if constexpr (WREG && STAGES == 3) {
     // 3-slot ring of pixel stages (8 KB each) + three register sets of weight fragments: per stage, wait until all but the
     // newest stage's 6 vector-memory instructions of this wave (2 DMA pieces + 4 fragment loads) are done, bare barrier,
     // refill the slot and the register set of the stage computed last with the stage two ahead
@@ -781,6 +820,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   constexpr int WCOLS = TCN * 32, RS = WCOLS + 4, WROWS = 32 * TPN;   // row stride padded: 16 lanes x float4 hit 16 bank groups
   constexpr int WTW = WROWS * RS + WROWS;                             // 4-byte words per wave: tile + one offset per row
   constexpr bool kLdsT = (KG > 1 ? 4 : 2) * WTW * 4 <= KG * ROWS * 128;
+  if constexpr (FEED && !kLdsT) { if (feeder) return; }   // (no barrier below in that case)
   // K groups: the reduction scratch lives in lds0_all and other waves may still be reading it -> all four in lds1_all
   float* const tl = reinterpret_cast<float*>(KG > 1 ? ep1 : (wave < 2 ? lds0_all : ep1)) + (KG > 1 ? wave : (wave & 1)) * WTW;
   constexpr int CPR = WCOLS / 4, RPI = 64 / CPR;   // 16-byte chunks per tile row, rows per wave instruction
@@ -793,6 +833,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
     // split layers (tools/ab_conv.py, FN2_CONV_DBG bit 2097152 of the ablation build).
     if constexpr (kLdsT) {
       if constexpr (STAGES >= 3) __syncthreads();  // the ring ends without a barrier: other waves may still read their last slot
+      if constexpr (FEED) { if (feeder) return; }
       int* rowoff = reinterpret_cast<int*>(tl + WROWS * RS);
 #pragma unroll
       for (int tp = 0; tp < TPN; ++tp) {
@@ -848,6 +889,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm2_kernel(const ConvArgs p)
   const bool wide = kLdsT && sizeof(OutT) == 4 && vec16 && c0 + wc * WCOLS + WCOLS <= p.Cout && !(p.dbg & 4194304);
   int* const rowoff = reinterpret_cast<int*>(tl + WROWS * RS);
   if constexpr (STAGES >= 3 && kLdsT) __syncthreads();  // (every wave: `wide` may differ between the cout halves of a block)
+  if constexpr (FEED) { if (feeder) return; }             // (the feeding waves took part in that barrier and have nothing to store)
 #pragma unroll
   for (int tc = 0; tc < TCN; ++tc) {
     const int cout_base = c0 + wc * TCN * 32 + tc * 32 + fh * 16;
@@ -1731,11 +1773,21 @@ static int launch2(const ConvArgs& a, int tile, int phases, hipStream_t s) {
           ah.fh_M = 0;
         }
         const ConvArgs& a = ah;   // (the launches below take the copy)
+        // FN2_WREG_FEED (default 1): the ring launches WITHOUT split-K take the eight-wave form (four waves feed the pixel ring,
+        // four multiply): FlowNet2 b4 3.657 -> 3.60 ms.  2: the K-split ring launches as well (measured with the ring on
+        // every WREG launch: 3.52 -> 3.63 ms, so not the default).  0: off.
+        const char* e_feed = getenv("FN2_WREG_FEED");
+        const int feed = e_feed ? atoi(e_feed) : 1;
         if (conv_name_sink().buf)
-          snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_igemm2_kernel<%s, %s, 4, 1, 1, 2, %d, 1, false, true, %s>",
-                   type_name<T>(), type_name<OutT>(), a.wfrag == 2 ? 3 : 2, slab ? "true" : "false");
+          snprintf(conv_name_sink().buf, conv_name_sink().cap, "conv_igemm2_kernel<%s, %s, 4, 1, 1, 2, %d, 1, false, true, %s%s>",
+                   type_name<T>(), type_name<OutT>(), a.wfrag == 2 ? 3 : 2, slab ? "true" : "false",
+                   (a.wfrag == 2 && (slab ? feed >= 2 : feed >= 1)) ? ", false, true" : "");
+        else if (a.wfrag == 2 && slab && feed >= 2)
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 3, 1, false, true, true, false, true>), grid, dim3(512), 0, s, a);
         else if (a.wfrag == 2 && slab)
           hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 3, 1, false, true, true>), grid, dim3(256), 0, s, a);
+        else if (a.wfrag == 2 && feed >= 1)
+          hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 3, 1, false, true, false, false, true>), grid, dim3(512), 0, s, a);
         else if (a.wfrag == 2)
           hipLaunchKernelGGL((conv_igemm2_kernel<T, OutT, 4, 1, 1, 2, 3, 1, false, true, false>), grid, dim3(256), 0, s, a);
         else if (slab)
